@@ -1,0 +1,193 @@
+/* mcamd.h -- C ABI of libmcamd.so, the MI355X (gfx950) hot path of
+ * modelcompression_amd: YOLOv2/Darknet-19 convolution forward/backward and the
+ * src/pruning mask kernels of AnishDelft/ModelCompression.
+ *
+ * The reference has no FFI layer: its operator API is
+ * Python calling torch.  Each entry point below names the reference call site it
+ * replaces.  Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no C++/torch types;
+ *   - every pointer is a DEVICE pointer into memory owned by the caller
+ *     (PyTorch-ROCm's allocator in practice); the library never allocates,
+ *     frees or retains device memory -- workspaces are caller-provided and sized
+ *     by the *_workspace_bytes queries;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     calls only enqueue work on it: no host synchronisation, graph-capturable;
+ *   - returns 0 on success, a negative MCAMD_E* code otherwise; the message is
+ *     available per host thread from mcamd_last_error(); nothing throws.
+ *
+ * Device data layouts
+ *   activation ("padded NHWC"): fp16 [B][H+2][W+2][ld], a one-pixel zero halo on
+ *     every side, `ld` channels per pixel (ld >= channels used, multiple of 8;
+ *     a tensor may be a channel slice [choff, choff+C) of a wider buffer -- that
+ *     is how route/concat is expressed).  The pointer passed is the address of
+ *     padded pixel (b=0, hp=0, wp=0), channel 0.  The halo must be zero and is
+ *     never written by the library; buffers should be followed by >= 64 bytes of
+ *     readable slack.
+ *   raw conv output / gradient wrt a block output: fp16 [B*H*W][ld] (no halo).
+ *   stem input (first layer, Cin = 3): padded NHWC with ld = 4 (channel 3 zero).
+ *   packed weights: fp16 [Npad][K], see mcamd_pack_weights.
+ *   master weights, masks, weight gradients: fp32 OIHW exactly as torch holds them.
+ */
+#ifndef MCAMD_H
+#define MCAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCAMD_OK 0
+#define MCAMD_EINVAL (-1)   /* bad argument / unsupported geometry */
+#define MCAMD_ELAUNCH (-2)  /* HIP launch error */
+#define MCAMD_EWORKSPACE (-3) /* workspace too small */
+
+int mcamd_version(void);              /* 100*major + minor */
+const char* mcamd_arch(void);         /* "gfx950" */
+const char* mcamd_last_error(void);   /* per-thread, never NULL */
+
+/* ------------------------------------------------------------------------- *
+ * Convolution geometry: k x k cross-correlation, stride 1, zero pad (k-1)/2,
+ * dilation 1, groups 1 -- the only form F.conv2d is called with on the hot
+ * path (reference src/pruning/weightPruning/layers.py:60-64 via nets.py:796-806).
+ * ------------------------------------------------------------------------- */
+typedef struct mcamd_conv_geom {
+    int32_t B, H, W;      /* batch, spatial size (output == input)            */
+    int32_t ksize;        /* 1 or 3                                           */
+    int32_t cin;          /* input channels consumed (multiple of 32), or 3 when stem != 0 */
+    int32_t cout;         /* output channels (any > 0)                        */
+    int32_t x_ld;         /* channels per pixel of the input buffer           */
+    int32_t x_choff;      /* first input channel inside the buffer            */
+    int32_t stem;         /* 1: first-layer form, x is NHWC4 (x_ld == 4), cin == 3, ksize == 3 */
+} mcamd_conv_geom;
+
+/* Output side of a convolution launch. */
+#define MCAMD_EPI_RAW_F16 0   /* y: fp16 [M][y_ld] + optional per-channel partial sums (BN batch statistics) */
+#define MCAMD_EPI_NCHW_F32 1  /* y: fp32 [B][cout][H][W] (+ bias)  -- the model's returned logits */
+#define MCAMD_EPI_PAD_F16 2   /* y: padded NHWC fp16, leaky(acc*scale[c]+shift[c]) (inference, BN folded) */
+typedef struct mcamd_conv_epilogue {
+    int32_t mode;
+    int32_t y_ld, y_choff;     /* modes 0 and 2 */
+    void* y;
+    const float* bias;         /* mode 1, may be NULL */
+    float* stats;              /* mode 0, may be NULL: fp32 [stats_rows][2][stats_ld]; row p holds the
+                                  sums (index 0) and sums of squares (index 1) over the pixels that
+                                  persistent workgroup p processed; rows the launch does not use are zeroed */
+    int32_t stats_rows, stats_ld;
+    const float* scale;        /* mode 2, may be NULL (=1) */
+    const float* shift;        /* mode 2, may be NULL (=0) */
+    float slope;               /* mode 2: negative-side slope (0.1 leaky, 1.0 linear) */
+} mcamd_conv_epilogue;
+
+/* Packed-weight sizes (elements of fp16) for a geometry. */
+int64_t mcamd_packed_elems_fwd(const mcamd_conv_geom* g);
+int64_t mcamd_packed_elems_dgrad(const mcamd_conv_geom* g);
+
+/* OIHW fp32 master (optionally * mask) -> fp16 kernel layouts.  Replaces the per-forward
+ * `self.weight * mask_var` of layers.py:59 (done once per optimizer step here).
+ *   fwd  : [Npad][t*cin + c]  = w[n][c][ty][tx],  t = ty*k + tx;  Npad = roundup(cout,128); pad rows zero
+ *          (stem: [Npad][ty*32 + tx*4 + c], other slots zero)
+ *   dgrad: [Cpad][t*cout_p + n] = w[n][c][k-1-ty][k-1-tx]; cout_p = roundup(cout,32); Cpad = roundup(cin,128)
+ * Either destination may be NULL. */
+int mcamd_pack_weights(const mcamd_conv_geom* g, const float* w_oihw, const float* mask_oihw,
+                       void* wp_fwd, void* wp_dgrad, void* stream);
+
+/* y = conv(x, w) -- replaces F.conv2d at layers.py:60-64. */
+int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const void* wp_fwd,
+                   const mcamd_conv_epilogue* epi, void* stream);
+
+/* dx = conv_transpose(dy, w) -- autograd's input gradient of the same call.
+ * `dy` is padded NHWC fp16 [B][H+2][W+2][dy_ld] (zero halo); g->cin/cout keep their forward
+ * meaning; the result has g->cin channels.  epi->mode 0 (fp16 [M][y_ld]) or 1 (fp32 NCHW). */
+int mcamd_conv_dgrad(const mcamd_conv_geom* g, const void* dy, int32_t dy_ld, int32_t dy_choff,
+                     const void* wp_dgrad, const mcamd_conv_epilogue* epi, void* stream);
+
+/* dW = wgrad(x, dy) * mask / grad_scale, written as fp32 OIHW -- autograd's weight gradient of
+ * `self.weight * mask_var` followed by F.conv2d.  Deterministic (slab reduction, no atomics).
+ * Filters whose mask row is entirely zero are skipped when `filter_keep` (device int32[cout],
+ * 0 = skip) is given.  `dbias` (fp32[cout], may be NULL) receives sum over pixels of dy / grad_scale. */
+size_t mcamd_conv_wgrad_workspace_bytes(const mcamd_conv_geom* g);
+int mcamd_conv_wgrad(const mcamd_conv_geom* g, const void* x, const void* dy, int32_t dy_ld,
+                     int32_t dy_choff, const float* mask_oihw, const int32_t* filter_keep,
+                     float grad_scale, float* dw_oihw, float* dbias, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * BatchNorm2d (eps, momentum as given; torch defaults 1e-5 / 0.1 at nets.py:802)
+ * + LeakyReLU(0.1) (nets.py:809) + MaxPool2d(2,2) (nets.py:821) + Reorg(2)
+ * (nets.py:648-667) + route/concat (nets.py:738-746), fused around the convs.
+ * ------------------------------------------------------------------------- */
+/* Batch statistics from the conv epilogue's partial sums -> affine coefficients.
+ * scale = gamma*invstd, shift = beta - mean*scale.  training != 0: batch stats (biased var),
+ * running stats updated with the unbiased var; training == 0: running stats. */
+int mcamd_bn_coeffs(const float* stats, int32_t stats_rows, int32_t stats_ld, int32_t C, int64_t count,
+                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    float momentum, float eps, int32_t training,
+                    float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
+
+#define MCAMD_DST_PLAIN 0  /* same resolution */
+#define MCAMD_DST_POOL 1   /* 2x2/2 max pool */
+#define MCAMD_DST_REORG 2  /* reorg stride 2: out channel = (hs*2+ws)*C + c at (h/2, w/2) */
+typedef struct mcamd_act_desc {
+    int32_t B, H, W, C;        /* conv output size */
+    const void* y; int32_t y_ld, y_choff;   /* raw conv output fp16 [B*H*W][y_ld] */
+    const float* scale; const float* shift; /* per channel */
+    float slope;               /* 0.1 (leaky) or 1.0 (linear) */
+    int32_t mode;              /* MCAMD_DST_* for dst */
+    void* dst; int32_t dst_ld, dst_choff;   /* padded NHWC fp16 at the mode's resolution */
+    void* dst2; int32_t dst2_ld, dst2_choff;/* optional second copy, PLAIN resolution (route of a pooled layer) */
+} mcamd_act_desc;
+int mcamd_bn_act_fwd(const mcamd_act_desc* d, void* stream);
+
+typedef struct mcamd_act_bwd_desc {
+    int32_t B, H, W, C;
+    const void* y; int32_t y_ld, y_choff;   /* saved raw conv output */
+    const float* scale; const float* shift; const float* mean; const float* invstd; /* from mcamd_bn_coeffs */
+    float slope;
+    int32_t mode;              /* how `g` maps onto this layer's output (MCAMD_DST_*) */
+    const void* g; int32_t g_ld, g_choff;   /* fp16 gradient wrt dst, [pixels at mode's resolution][g_ld] */
+    const void* g2; int32_t g2_ld, g2_choff;/* optional gradient wrt dst2 (PLAIN resolution) */
+    void* dy; int32_t dy_ld, dy_choff;      /* out: padded NHWC fp16 gradient wrt raw conv output */
+    float* dgamma; float* dbeta;            /* out fp32 [C], already divided by grad_scale; NULL when has_bn == 0 */
+    int32_t has_bn;            /* 0: y -> activation only (scale/shift ignored: identity) */
+    float grad_scale;
+} mcamd_act_bwd_desc;
+size_t mcamd_bn_act_bwd_workspace_bytes(const mcamd_act_bwd_desc* d);
+int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Layout conversion at the model boundary (Darknet.forward takes/returns NCHW fp32,
+ * nets.py:720-774).
+ * ------------------------------------------------------------------------- */
+/* src fp32 [B][C][H][W] * mul -> dst padded NHWC fp16 channels [choff, choff+C). */
+int mcamd_nchw_f32_to_padded_nhwc_f16(const float* src, int32_t B, int32_t C, int32_t H, int32_t W,
+                                      float mul, void* dst, int32_t dst_ld, int32_t dst_choff, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Pruning (reference src/pruning/weightPruning/methods.py).
+ * ------------------------------------------------------------------------- */
+/* k-th smallest |w| (0-based, ascending) over `nseg` fp32 tensors -- the order statistic
+ * np.percentile selects at methods.py:18.  Writes s[k] and s[min(k+1, n-1)] as two fp32 values to
+ * `out2` (device).  ptrs/counts are HOST arrays of device pointers / element counts. */
+size_t mcamd_kth_magnitude_workspace_bytes(void);
+int mcamd_kth_magnitude(const float* const* ptrs, const int64_t* counts, int32_t nseg, int64_t k,
+                        float* out2, void* workspace, size_t workspace_bytes, void* stream);
+/* mask[i] = |w[i]| > *threshold ? 1.f : 0.f  (strict, methods.py:24-25); threshold is a device fp32. */
+int mcamd_magnitude_mask(const float* w, int64_t n, const float* threshold, float* mask, void* stream);
+/* Per-filter score of methods.py:43-51 in numpy's fp32 summation order:
+ * out[o] = (mean_sq[o] / sqrt(sum_o mean_sq^2)) / max_o(...), one launch per conv layer. */
+size_t mcamd_filter_scores_workspace_bytes(int32_t cout);
+int mcamd_filter_scores(const float* w_oihw, int32_t cout, int32_t cin, int32_t kh, int32_t kw,
+                        float* scores, void* workspace, size_t workspace_bytes, void* stream);
+/* mask[o][...] = keep[o] ? 1.f : 0.f over a [cout][per_filter] tensor (methods.py:74). */
+int mcamd_filter_mask(const int32_t* keep, int32_t cout, int64_t per_filter, float* mask, void* stream);
+/* count of exact zeros in an fp32 tensor, added to *out (device int64) -- prune_rate, utils.py:76-80. */
+int mcamd_count_zeros(const float* w, int64_t n, unsigned long long* out, void* stream);
+/* sum(p * |m - 1|) accumulated in fp32 into *out -- are_masks_consistent, utils.py:122-133. */
+int mcamd_masked_residual(const float* w, const float* mask, int64_t n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCAMD_H */

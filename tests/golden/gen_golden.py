@@ -1,0 +1,421 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by IMPORTING THE REFERENCE (build container only).
+
+    python tests/golden/gen_golden.py            # writes the fixtures next to this file
+
+The reference (/root/reference, read-only) never travels to the GPU box; the small
+fixtures written here do.  While generating, every oracle restatement
+(oracle/prune_ref.py, oracle/darknet_ref.py) is cross-checked against the
+reference -- a mismatch aborts the run, so committed fixtures imply
+oracle == reference on these inputs.
+
+Import shims: src/nets.py does `import cv2` and
+`from torchvision import models`, neither of which is used on the Darknet path and
+neither of which is installed; empty modules of those names are registered before
+the import.  No reference code is modified or copied.
+"""
+import contextlib
+import hashlib
+import io
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+for _name in ("cv2", "torchvision", "torchvision.models"):
+    sys.modules.setdefault(_name, types.ModuleType(_name))
+sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+
+with contextlib.redirect_stdout(io.StringIO()):
+    from src import nets as ref_nets                                   # noqa: E402
+    from src.pruning.weightPruning import layers as ref_layers         # noqa: E402
+    from src.pruning.weightPruning import methods as ref_methods       # noqa: E402
+    from src.pruning.weightPruning import utils as ref_utils           # noqa: E402
+
+from oracle import darknet_ref as O                                    # noqa: E402
+from oracle import prune_ref as P                                      # noqa: E402
+
+YOLO_CFG_REF = os.path.join(REF, "src", "yolov2-voc.cfg")
+YOLO_CFG = os.path.join(REPO, "modelcompression_amd", "cfg", "yolov2-voc.cfg")
+MINI_CFG = os.path.join(HERE, "mini.cfg")
+TRICKY_CFG = os.path.join(HERE, "tricky.cfg")
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def bits32(x):
+    return int(np.float32(x).view(np.uint32))
+
+
+def bits64(x):
+    return int(np.float64(x).view(np.uint64))
+
+
+def sha(arr):
+    return hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest()
+
+
+def ref_model(cfg, state):
+    m = quiet(ref_nets.Darknet, cfg)
+    m.load_state_dict(state)
+    return m
+
+
+def np_params(model):
+    return [p.detach().numpy() for p in model.parameters()]
+
+
+def check(cond, what):
+    if not cond:
+        raise SystemExit("ORACLE != REFERENCE: " + what)
+    print("  ok:", what)
+
+
+def dump_json(name, obj):
+    with open(os.path.join(HERE, name), "w") as f:
+        json.dump(obj, f, indent=1, sort_keys=True)
+    print("wrote", name)
+
+
+# ---------------------------------------------------------------------------
+def gen_cfg():
+    out = {
+        "yolov2_voc": ref_nets.parse_cfg(YOLO_CFG_REF),
+        "tricky": ref_nets.parse_cfg(TRICKY_CFG),
+        "mini": ref_nets.parse_cfg(MINI_CFG),
+    }
+    check(O.parse_cfg(YOLO_CFG) == out["yolov2_voc"], "parse_cfg(our yolov2-voc.cfg) == reference parse of its own cfg")
+    check(O.parse_cfg(TRICKY_CFG) == out["tricky"], "parse_cfg(tricky.cfg)")
+    check(O.parse_cfg(MINI_CFG) == out["mini"], "parse_cfg(mini.cfg)")
+    dump_json("cfg_blocks.json", out)
+
+
+def gen_structure():
+    out = {}
+    for tag, cfg in (("yolov2_voc", YOLO_CFG_REF), ("mini", MINI_CFG)):
+        m = quiet(ref_nets.Darknet, cfg)
+        sd = m.state_dict()
+        out[tag] = {
+            "n_models": len(m.models),
+            "module_classes": [type(x).__name__ for x in m.models],
+            "state_dict": [[k, list(v.shape), str(v.dtype)] for k, v in sd.items()],
+            "param_names": [k for k, _ in m.named_parameters()],
+            "n_params": int(sum(p.numel() for p in m.parameters())),
+            "width": m.width, "height": m.height, "anchors": m.anchors,
+            "num_anchors": m.num_anchors, "anchor_step": m.anchor_step, "num_classes": m.num_classes,
+            "header": m.header.tolist(), "seen": int(m.seen),
+        }
+        blocks = O.parse_cfg(cfg)
+        st = O.init_state(blocks, seed=0)
+        check(list(st.keys()) == list(sd.keys()), tag + ": oracle state keys == reference state_dict keys")
+        check(O.param_keys(blocks) == out[tag]["param_names"], tag + ": parameter order")
+    dump_json("model_structure.json", out)
+
+
+def gen_mini_fwd_bwd():
+    blocks = O.parse_cfg(MINI_CFG)
+    state = O.init_state(blocks, seed=0)
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(2, 3, 64, 64, generator=g)
+    gout = torch.randn(2, 125, 16, 16, generator=g)
+    arrays = {"x": x.numpy(), "gout": gout.numpy()}
+
+    # reference: eval forward, then one train forward/backward
+    m = ref_model(MINI_CFG, state)
+    m.eval()
+    with torch.no_grad():
+        arrays["eval_logits"] = m(x).numpy().copy()
+    m.train()
+    feats = {}
+    hooks = [mod.register_forward_hook(lambda _m, _i, o, i=i: feats.__setitem__(i, o.detach().clone()))
+             for i, mod in enumerate(m.models) if type(mod).__name__ != "RegionLoss"]
+    xr = x.clone().requires_grad_(True)
+    out = m(xr)
+    out.backward(gout)
+    for h in hooks:
+        h.remove()
+    arrays["train_logits"] = out.detach().numpy().copy()
+    arrays["grad_x"] = xr.grad.numpy().copy()
+    for i, v in feats.items():
+        arrays["out_%d" % i] = v.numpy()
+    for k, p in m.named_parameters():
+        arrays["grad/" + k] = p.grad.numpy().copy()
+    for k, v in m.state_dict().items():
+        if "running_" in k:
+            arrays["after/" + k] = v.numpy().copy()
+
+    # oracle on the same inputs
+    st2 = {k: v.clone() for k, v in state.items()}
+    with torch.no_grad():
+        ev = O.forward(blocks, st2, x, training=False)
+    check(torch.equal(ev, torch.from_numpy(arrays["eval_logits"])), "mini eval logits bit-equal")
+    for k in O.param_keys(blocks):
+        st2[k].requires_grad_(True)
+    rec = {}
+    x2 = x.clone().requires_grad_(True)
+    o2 = O.forward(blocks, st2, x2, training=True, record=rec)
+    o2.backward(gout)
+    check(torch.equal(o2.detach(), out.detach()), "mini train logits bit-equal")
+    check(torch.equal(x2.grad, xr.grad), "mini grad_x bit-equal")
+    for k in O.param_keys(blocks):
+        check(torch.equal(st2[k].grad, torch.from_numpy(arrays["grad/" + k])), "mini grad " + k)
+    for k in st2:
+        if "running_" in k:
+            check(torch.equal(st2[k], torch.from_numpy(arrays["after/" + k])), "mini " + k + " after step")
+    for i, v in feats.items():
+        if i in rec:
+            check(torch.equal(rec[i].detach(), v), "mini block output %d" % i)
+    np.savez_compressed(os.path.join(HERE, "mini_fwd_bwd.npz"), **arrays)
+    print("wrote mini_fwd_bwd.npz")
+
+
+def gen_layer_cases():
+    """MaskedConv2d fwd / dgrad / wgrad with and without a mask (layers.py:33-64)."""
+    arrays = {}
+    g = torch.Generator().manual_seed(2)
+    cases = [("c3", 2, 32, 64, 3, 16), ("c1", 2, 64, 32, 1, 8), ("c3bias", 1, 32, 32, 3, 8)]
+    for tag, B, cin, cout, k, H in cases:
+        x = torch.randn(B, cin, H, H, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g) * 0.1
+        b = torch.randn(cout, generator=g) * 0.1 if "bias" in tag else None
+        gy = torch.randn(B, cout, H, H, generator=g)
+        mask = (torch.rand(cout, cin, k, k, generator=g) > 0.6).float()
+        mask[1] = 0.0                                   # one whole filter pruned
+        for masked in (0, 1):
+            conv = ref_layers.MaskedConv2d(cin, cout, k, 1, (k - 1) // 2, bias=b is not None)
+            conv.weight.data.copy_(w)
+            if b is not None:
+                conv.bias.data.copy_(b)
+            if masked:
+                conv.set_mask(mask.clone())
+            xr = x.clone().requires_grad_(True)
+            y = conv(xr)
+            y.backward(gy)
+            pre = "%s_m%d_" % (tag, masked)
+            arrays[pre + "y"] = y.detach().numpy()
+            arrays[pre + "dx"] = xr.grad.numpy()
+            arrays[pre + "dw"] = conv.weight.grad.numpy()
+            arrays[pre + "w_after_set_mask"] = conv.weight.detach().numpy().copy()
+            if b is not None:
+                arrays[pre + "db"] = conv.bias.grad.numpy()
+            # oracle: F.conv2d(x, w*mask)
+            w2 = (w * mask if masked else w).clone().requires_grad_(True)
+            wl = w2
+            if masked:
+                wl = w2 * mask
+            x2 = x.clone().requires_grad_(True)
+            y2 = torch.nn.functional.conv2d(x2, wl, b, 1, (k - 1) // 2)
+            y2.backward(gy)
+            check(torch.equal(y2.detach(), y.detach()) and torch.equal(x2.grad, xr.grad)
+                  and torch.equal(w2.grad, conv.weight.grad), "MaskedConv2d case " + pre)
+        arrays[tag + "_x"], arrays[tag + "_w"], arrays[tag + "_gy"], arrays[tag + "_mask"] = \
+            x.numpy(), w.numpy(), gy.numpy(), mask.numpy()
+        if b is not None:
+            arrays[tag + "_b"] = b.numpy()
+    np.savez_compressed(os.path.join(HERE, "layer_cases.npz"), **arrays)
+    print("wrote layer_cases.npz")
+
+
+def mask_digest(masks):
+    return {
+        "kept": [int(m.sum()) for m in masks],
+        "sha256_packbits": [sha(np.packbits(m.reshape(-1) != 0)) for m in masks],
+    }
+
+
+def gen_prune(tag, cfg, wperc, fperc, store_scores):
+    blocks = O.parse_cfg(cfg)
+    state = O.init_state(blocks, seed=0)
+    m = ref_model(cfg, state)
+    params = np_params(m)
+    out = {"n_weights": int(sum(p.size for p in params if p.ndim != 1)),
+           "n_filters": int(sum(p.shape[0] for p in params if p.ndim == 4))}
+    # also exercise exact zeros / ties: zero one filter and one tap plane before pruning
+    for perc in wperc:
+        masks = quiet(ref_methods.weight_prune, m, perc)
+        om, thr = P.weight_prune(params, perc)
+        k, gamma, above = P.virtual_index(out["n_weights"], perc, np.float32)
+        for a, b in zip(masks, om):
+            check(np.array_equal(a.numpy(), b), "%s weight_prune(%s) mask bit-equal" % (tag, perc))
+        d = mask_digest(om)
+        d.update({"threshold_bits": bits32(thr), "k": k, "gamma_bits": bits32(gamma)})
+        out["weight_%g" % perc] = d
+    scores_npz = {}
+    for perc in fperc:
+        masks = quiet(ref_methods.quick_filter_prune, m, perc)
+        om, info = P.quick_filter_prune(params, perc)
+        for a, b in zip(masks, om):
+            check(np.array_equal(a.numpy(), b), "%s quick_filter_prune(%s) mask bit-equal" % (tag, perc))
+        d = mask_digest(om)
+        d.update({"threshold_bits64": bits64(info["threshold"]),
+                  "pruned": [ix.tolist() for ix in info["pruned"]],
+                  "scores_sha256": sha(np.concatenate(info["scores"]))})
+        out["filter_%g" % perc] = d
+        scores_npz["scores"] = np.concatenate(info["scores"]).view(np.uint32)
+    # prune_rate / consistency after set_masks (utils.py:59-133, nets.py:1053-1061)
+    perc = wperc[-1]
+    masks = quiet(ref_methods.weight_prune, m, perc)
+    m.set_masks(masks)
+    pr = quiet(ref_utils.prune_rate, m, True)
+    params_after = np_params(m)
+    check(P.prune_rate(params_after) == pr, tag + " prune_rate after set_masks")
+    check(ref_utils.are_masks_consistent(m, masks) == P.are_masks_consistent(params_after, [x.numpy() for x in masks]),
+          tag + " are_masks_consistent")
+    out["after_weight_%g" % perc] = {
+        "prune_rate": pr, "layer_rates": P.layer_prune_rates(params_after),
+        "consistent": bool(ref_utils.are_masks_consistent(m, masks)),
+        "state_keys_with_mask": [k for k in m.state_dict().keys() if k.endswith(".mask")][:3],
+    }
+    if store_scores:
+        np.savez_compressed(os.path.join(HERE, "prune_%s_scores.npz" % tag), **scores_npz)
+    return out
+
+
+def gen_prune_small_edge():
+    """arg_nonzero_min quirks (utils.py:96-120) and the greedy filter_prune (methods.py:81-142)."""
+    out = {"arg_nonzero_min": []}
+    for a in ([], [0.0, 0.0], [3.0, 0.0, 0.0], [0.0, 2.0, 1.0, 0.0], [5.0, 2.0, 7.0], [0.0, 0.0, 4.0], [1.0]):
+        r = quiet(ref_utils.arg_nonzero_min, list(a))
+        o = P.arg_nonzero_min(list(a))
+        check((r is None and o is None) or tuple(map(float, r)) == tuple(map(float, o)), "arg_nonzero_min(%s)" % a)
+        out["arg_nonzero_min"].append([a, None if r is None else [float(r[0]), float(r[1])]])
+    # Greedy variant.  The reference's filter_prune() (methods.py:128-142) cannot terminate on a
+    # Darknet: prune_one_filter builds *numpy* masks, MaskedConv2d.set_mask -> register_buffer
+    # rejects a numpy array, and Darknet.set_masks swallows that in its bare `except: pass`
+    # (nets.py:1059-1060), so prune_rate never moves.  Pin prune_one_filter step by step instead,
+    # applying each mask as tensors the way a working set_masks would.
+    blocks = O.parse_cfg(MINI_CFG)
+    state = O.init_state(blocks, seed=0)
+    m = ref_model(MINI_CFG, state)
+    params = [p.copy() for p in np_params(m)]
+    rmasks, omasks, order = [], [], []
+    for _ in range(4):
+        rmasks = quiet(ref_methods.prune_one_filter, m, rmasks)
+        omasks, layer, filt = P.prune_one_filter(params, omasks)
+        for a, b in zip(rmasks, omasks):
+            check(np.array_equal(np.asarray(a), b), "mini prune_one_filter step %d masks" % len(order))
+        order.append([layer, filt])
+        m.set_masks([torch.from_numpy(np.asarray(a)) for a in rmasks])
+        for p, mk in zip([p for p in params if p.ndim == 4], omasks):
+            p *= mk
+        check(quiet(ref_utils.prune_rate, m, False) == P.prune_rate(params), "prune_rate after greedy step")
+    out["mini_prune_one_filter"] = {"order": order, "kept": [int(x.sum()) for x in omasks],
+                                    "prune_rate": P.prune_rate(params)}
+    return out
+
+
+def gen_yolo_logits():
+    blocks = O.parse_cfg(YOLO_CFG)
+    state = O.init_state(blocks, seed=0)
+    m = ref_model(YOLO_CFG_REF, state)
+    tmp = "/tmp/_gen_golden_yolo.weights"
+    m.seen = 12345
+    m.save_weights(tmp)
+    digest = hashlib.sha256(open(tmp, "rb").read()).hexdigest()
+    size = os.path.getsize(tmp)
+    # round trip through the reference reader into a fresh model
+    m2 = quiet(ref_nets.Darknet, YOLO_CFG_REF)
+    quiet(m2.load_weights, tmp)
+    m2.eval()
+    x = torch.rand(1, 3, 416, 416, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        logits = m2(x)
+    # oracle: write the same file, read it back, same logits
+    tmp2 = "/tmp/_gen_golden_yolo2.weights"
+    O.save_weights(blocks, state, tmp2, seen=12345)
+    check(hashlib.sha256(open(tmp2, "rb").read()).hexdigest() == digest, "save_weights file bytes identical")
+    st2 = O.init_state(blocks, seed=99)
+    seen = O.load_weights(blocks, st2, tmp)
+    check(seen == 12345, "load_weights header 'seen'")
+    with torch.no_grad():
+        ol = O.forward(blocks, st2, x, training=False)
+    check(torch.equal(ol, logits), "yolov2-voc eval logits bit-equal (B=1)")
+    os.remove(tmp), os.remove(tmp2)
+    np.savez_compressed(os.path.join(HERE, "yolo_logits_b1.npz"), logits=logits.numpy())
+    print("wrote yolo_logits_b1.npz")
+    return {"weights_sha256": digest, "weights_bytes": size, "seen": 12345, "x_seed": 3, "state_seed": 0}
+
+
+def gen_sgd():
+    """Two masked SGD steps on the mini model (train.py:144-147, 224-235)."""
+    blocks = O.parse_cfg(MINI_CFG)
+    state = O.init_state(blocks, seed=0)
+    m = ref_model(MINI_CFG, state)
+    masks = quiet(ref_methods.weight_prune, m, 60.0)
+    m.set_masks(masks)
+    B = 2
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3, momentum=0.9, dampening=0, weight_decay=0.0005 * B)
+    g = torch.Generator().manual_seed(4)
+    xs = [torch.rand(B, 3, 64, 64, generator=g) for _ in range(2)]
+    gos = [torch.randn(B, 125, 16, 16, generator=g) for _ in range(2)]
+    arrays = {"x0": xs[0].numpy(), "x1": xs[1].numpy(), "g0": gos[0].numpy(), "g1": gos[1].numpy()}
+    # oracle mirror
+    st = {k: v.clone() for k, v in state.items()}
+    keys = O.param_keys(blocks)
+    convk = [k for k in keys if st[k].dim() == 4]
+    om = [mk.clone() for mk in masks]
+    for k, mk in zip(convk, om):
+        st[k].mul_(mk)
+    bufs = [None] * len(keys)
+    m.train()
+    for step in range(2):
+        out = m(xs[step])
+        opt.zero_grad()
+        out.backward(gos[step])
+        opt.step()
+        for k in keys:
+            st[k].requires_grad_(True)
+            st[k].grad = None
+        o2 = O.forward(blocks, st, xs[step], training=True, masks=om)
+        o2.backward(gos[step])
+        with torch.no_grad():
+            ps = [st[k] for k in keys]
+            O.sgd_step([p.data for p in ps], [p.grad for p in ps], bufs, 1e-3, 0.9, 0.0005 * B)
+        for k in keys:
+            st[k].requires_grad_(False)
+        sd = m.state_dict()
+        for k in keys:
+            # torch.optim.SGD fuses `g + wd*p` / `p - lr*buf` (add with alpha); the oracle's
+            # two-rounding restatement may differ in the last bit, so this one is a tolerance.
+            check(torch.allclose(sd[k], st[k], rtol=1e-5, atol=1e-7), "sgd step %d param %s (rtol 1e-5, max abs diff %.3g)" % (step, k, float((sd[k] - st[k]).abs().max())))
+            if sd[k].dim() == 4:
+                mk = masks[convk.index(k)]
+                check(bool((sd[k][mk == 0] == 0).all()), "masked weights exactly 0 after step %d: %s" % (step, k))
+            arrays["step%d/%s" % (step, k)] = sd[k].numpy().copy()
+    check(ref_utils.are_masks_consistent(m, masks), "masks consistent after 2 SGD steps")
+    for i, mk in enumerate(masks):
+        arrays["mask%d" % i] = mk.numpy()
+    np.savez_compressed(os.path.join(HERE, "sgd_step.npz"), **arrays)
+    print("wrote sgd_step.npz")
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    gen_cfg()
+    gen_structure()
+    gen_mini_fwd_bwd()
+    gen_layer_cases()
+    gen_sgd()
+    prune = {"mini": gen_prune("mini", MINI_CFG, [30.0, 50.0, 80.0], [40.0, 60.0], True)}
+    prune["edge"] = gen_prune_small_edge()
+    if "--skip-full" not in sys.argv:
+        prune["yolov2_voc"] = gen_prune("yolov2_voc", YOLO_CFG_REF, [30.0, 80.0], [40.0, 60.0], True)
+        prune["yolo_io"] = gen_yolo_logits()
+    prune["versions"] = {"numpy": np.__version__, "torch": torch.__version__}
+    dump_json("prune_golden.json", prune)
+
+
+if __name__ == "__main__":
+    main()
