@@ -55,7 +55,9 @@ const char* mcamd_last_error(void);   /* per-thread, never NULL */
 typedef struct mcamd_conv_geom {
     int32_t B, H, W;      /* batch, spatial size (output == input)            */
     int32_t ksize;        /* 1 or 3                                           */
-    int32_t cin;          /* input channels consumed (multiple of 32), or 3 when stem != 0 */
+    int32_t cin;          /* input channels of the weight tensor (any > 0).  The kernels consume
+                             round_up(cin, 32) channels per pixel: the buffer slice must be that wide
+                             and the extra channels must hold zeros.  3 when stem != 0. */
     int32_t cout;         /* output channels (any > 0)                        */
     int32_t x_ld;         /* channels per pixel of the input buffer           */
     int32_t x_choff;      /* first input channel inside the buffer            */
@@ -72,13 +74,17 @@ typedef struct mcamd_conv_epilogue {
     void* y;
     const float* bias;         /* mode 1, may be NULL */
     float* stats;              /* mode 0, may be NULL: fp32 [stats_rows][2][stats_ld]; row p holds the
-                                  sums (index 0) and sums of squares (index 1) over the pixels that
-                                  persistent workgroup p processed; rows the launch does not use are zeroed */
-    int32_t stats_rows, stats_ld;
+                                  per-channel sums (index 0) and sums of squares (index 1) over the pixels
+                                  that persistent workgroup p processed (fixed order: deterministic) */
+    int32_t stats_rows;        /* must equal mcamd_conv_stats_rows(geom) */
+    int32_t stats_ld;          /* >= round_up(cout, 128) */
     const float* scale;        /* mode 2, may be NULL (=1) */
     const float* shift;        /* mode 2, may be NULL (=0) */
     float slope;               /* mode 2: negative-side slope (0.1 leaky, 1.0 linear) */
 } mcamd_conv_epilogue;
+
+/* Rows of the BatchNorm partial-sum slab a forward launch of this geometry writes. */
+int32_t mcamd_conv_stats_rows(const mcamd_conv_geom* g);
 
 /* Packed-weight sizes (elements of fp16) for a geometry. */
 int64_t mcamd_packed_elems_fwd(const mcamd_conv_geom* g);
@@ -149,9 +155,8 @@ typedef struct mcamd_act_bwd_desc {
     const void* g; int32_t g_ld, g_choff;   /* fp16 gradient wrt dst, [pixels at mode's resolution][g_ld] */
     const void* g2; int32_t g2_ld, g2_choff;/* optional gradient wrt dst2 (PLAIN resolution) */
     void* dy; int32_t dy_ld, dy_choff;      /* out: padded NHWC fp16 gradient wrt raw conv output */
-    float* dgamma; float* dbeta;            /* out fp32 [C], already divided by grad_scale; NULL when has_bn == 0 */
-    int32_t has_bn;            /* 0: y -> activation only (scale/shift ignored: identity) */
-    float grad_scale;
+    float* dgamma; float* dbeta;            /* out fp32 [C], already divided by grad_scale (may be NULL) */
+    float grad_scale;          /* the incoming gradients are grad_scale x the true ones (fp16 range) */
 } mcamd_act_bwd_desc;
 size_t mcamd_bn_act_bwd_workspace_bytes(const mcamd_act_bwd_desc* d);
 int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, size_t workspace_bytes, void* stream);

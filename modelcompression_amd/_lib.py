@@ -1,0 +1,114 @@
+"""ctypes binding of libmcamd.so (include/mcamd.h).
+
+The product path has no CPU or PyTorch fallback: if the HIP library cannot be
+loaded this raises, and every wrapper raises `McamdError` on a non-zero return.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmcamd.so")
+
+
+class McamdError(RuntimeError):
+    pass
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("ksize", C.c_int32),
+                ("cin", C.c_int32), ("cout", C.c_int32), ("x_ld", C.c_int32), ("x_choff", C.c_int32),
+                ("stem", C.c_int32)]
+
+
+class ConvEpilogue(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("y_ld", C.c_int32), ("y_choff", C.c_int32),
+                ("y", C.c_void_p), ("bias", C.c_void_p), ("stats", C.c_void_p),
+                ("stats_rows", C.c_int32), ("stats_ld", C.c_int32),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("slope", C.c_float)]
+
+
+class ActDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("y", C.c_void_p), ("y_ld", C.c_int32), ("y_choff", C.c_int32),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("slope", C.c_float), ("mode", C.c_int32),
+                ("dst", C.c_void_p), ("dst_ld", C.c_int32), ("dst_choff", C.c_int32),
+                ("dst2", C.c_void_p), ("dst2_ld", C.c_int32), ("dst2_choff", C.c_int32)]
+
+
+class ActBwdDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("y", C.c_void_p), ("y_ld", C.c_int32), ("y_choff", C.c_int32),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
+                ("slope", C.c_float), ("mode", C.c_int32),
+                ("g", C.c_void_p), ("g_ld", C.c_int32), ("g_choff", C.c_int32),
+                ("g2", C.c_void_p), ("g2_ld", C.c_int32), ("g2_choff", C.c_int32),
+                ("dy", C.c_void_p), ("dy_ld", C.c_int32), ("dy_choff", C.c_int32),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("grad_scale", C.c_float)]
+
+
+EPI_RAW_F16, EPI_NCHW_F32, EPI_PAD_F16 = 0, 1, 2
+DST_PLAIN, DST_POOL, DST_REORG = 0, 1, 2
+
+# name -> (restype, argtypes); the complete list of symbols include/mcamd.h declares.
+_P, _I32, _I64, _F, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+SIGNATURES = {
+    "mcamd_version": (C.c_int, []),
+    "mcamd_arch": (C.c_char_p, []),
+    "mcamd_last_error": (C.c_char_p, []),
+    "mcamd_conv_stats_rows": (_I32, [C.POINTER(ConvGeom)]),
+    "mcamd_packed_elems_fwd": (_I64, [C.POINTER(ConvGeom)]),
+    "mcamd_packed_elems_dgrad": (_I64, [C.POINTER(ConvGeom)]),
+    "mcamd_pack_weights": (C.c_int, [C.POINTER(ConvGeom), _P, _P, _P, _P, _P]),
+    "mcamd_conv_fwd": (C.c_int, [C.POINTER(ConvGeom), _P, _P, C.POINTER(ConvEpilogue), _P]),
+    "mcamd_conv_dgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _I32, _I32, _P, C.POINTER(ConvEpilogue), _P]),
+    "mcamd_conv_wgrad_workspace_bytes": (_SZ, [C.POINTER(ConvGeom)]),
+    "mcamd_conv_wgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _P, _I32, _I32, _P, _P, _F, _P, _P, _P, _SZ, _P]),
+    "mcamd_bn_coeffs": (C.c_int, [_P, _I32, _I32, _I32, _I64, _P, _P, _P, _P, _F, _F, _I32, _P, _P, _P, _P, _P]),
+    "mcamd_bn_act_fwd": (C.c_int, [C.POINTER(ActDesc), _P]),
+    "mcamd_bn_act_bwd_workspace_bytes": (_SZ, [C.POINTER(ActBwdDesc)]),
+    "mcamd_bn_act_bwd": (C.c_int, [C.POINTER(ActBwdDesc), _P, _SZ, _P]),
+    "mcamd_nchw_f32_to_padded_nhwc_f16": (C.c_int, [_P, _I32, _I32, _I32, _I32, _F, _P, _I32, _I32, _P]),
+    "mcamd_kth_magnitude_workspace_bytes": (_SZ, []),
+    "mcamd_kth_magnitude": (C.c_int, [C.POINTER(_P), C.POINTER(_I64), _I32, _I64, _P, _P, _SZ, _P]),
+    "mcamd_magnitude_mask": (C.c_int, [_P, _I64, _P, _P, _P]),
+    "mcamd_filter_scores_workspace_bytes": (_SZ, [_I32]),
+    "mcamd_filter_scores": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _SZ, _P]),
+    "mcamd_filter_mask": (C.c_int, [_P, _I32, _I64, _P, _P]),
+    "mcamd_count_zeros": (C.c_int, [_P, _I64, _P, _P]),
+    "mcamd_masked_residual": (C.c_int, [_P, _P, _I64, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises McamdError when it is absent (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise McamdError(
+                "libmcamd.so is missing (%s). Build it with `python -m modelcompression_amd.build`; "
+                "modelcompression_amd has no CPU/PyTorch fallback for its compute path." % LIB_PATH)
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)          # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().mcamd_last_error().decode()
+        raise McamdError("%s failed (%d): %s" % (what or "mcamd call", rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,299 @@
+// C-ABI entry points of libmcamd.so (see include/mcamd.h): argument validation, geometry ->
+// launch descriptors, weight packing.  No allocation, no synchronisation.
+#include <stdarg.h>
+#include <string.h>
+
+#include "kernels.h"
+
+static thread_local char g_err[512] = "";
+
+void mcamd_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int mcamd_version(void) { return 100; }
+extern "C" const char* mcamd_arch(void) { return "gfx950"; }
+extern "C" const char* mcamd_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------
+// geometry helpers
+// ---------------------------------------------------------------------------------------
+static int cin_tap_of(const mcamd_conv_geom* g) { return g->stem ? 32 : round_up_int(g->cin, 32); }
+static int ntaps_of(const mcamd_conv_geom* g) { return g->stem ? 3 : g->ksize * g->ksize; }
+static int cout_p_of(const mcamd_conv_geom* g) { return round_up_int(g->cout, 32); }
+
+static int check_geom(const mcamd_conv_geom* g, const char* what) {
+    MCAMD_REQUIRE(g, "%s: null geometry", what);
+    MCAMD_REQUIRE(g->B > 0 && g->H > 0 && g->W > 0 && g->cin > 0 && g->cout > 0, "%s: non-positive dimension", what);
+    MCAMD_REQUIRE(g->ksize == 1 || g->ksize == 3, "%s: ksize %d unsupported (1 or 3)", what, g->ksize);
+    MCAMD_REQUIRE((long long)g->B * g->H * g->W < (1ll << 31), "%s: more than 2^31 output pixels", what);
+    if (g->stem) {
+        MCAMD_REQUIRE(g->cin == 3 && g->ksize == 3 && g->x_ld == 4 && g->x_choff == 0,
+                      "%s: stem form needs cin=3, ksize=3, x_ld=4, x_choff=0", what);
+    } else {
+        MCAMD_REQUIRE(g->x_ld % 8 == 0 && g->x_choff % 8 == 0, "%s: x_ld / x_choff must be multiples of 8", what);
+        MCAMD_REQUIRE(g->x_choff + cin_tap_of(g) <= g->x_ld, "%s: x channel slice [%d, %d) exceeds x_ld %d", what,
+                      g->x_choff, g->x_choff + cin_tap_of(g), g->x_ld);
+    }
+    return MCAMD_OK;
+}
+
+// tap table relative to the row base = padded pixel (h, w) of output pixel (h, w), i.e. the
+// top-left corner of its 3x3 window.
+static void fill_taps(int ksize, int stem, int row_stride, int ld, int* taps) {
+    if (stem) {
+        for (int ty = 0; ty < 3; ++ty) taps[ty] = ty * row_stride;
+    } else if (ksize == 3) {
+        for (int ty = 0; ty < 3; ++ty)
+            for (int tx = 0; tx < 3; ++tx) taps[ty * 3 + tx] = ty * row_stride + tx * ld;
+    } else {
+        taps[0] = row_stride + ld;  // centre pixel
+    }
+}
+
+extern "C" int64_t mcamd_packed_elems_fwd(const mcamd_conv_geom* g) {
+    if (!g) return 0;
+    return (int64_t)round_up_int(g->cout, 128) * ntaps_of(g) * cin_tap_of(g);
+}
+extern "C" int64_t mcamd_packed_elems_dgrad(const mcamd_conv_geom* g) {
+    if (!g || g->stem) return 0;
+    return (int64_t)round_up_int(g->cin, 128) * g->ksize * g->ksize * cout_p_of(g);
+}
+
+// ---------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_fwd_kernel(const float* w, const float* mask, half_t* wp, int Cout, int Cin,
+                                                       int ks, int cin_tap, int stem, long long total, int ktot) {
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        int n = (int)(idx / ktot);
+        int k = (int)(idx - (long long)n * ktot);
+        float v = 0.f;
+        if (n < Cout) {
+            int c, ty, tx;
+            bool ok;
+            if (stem) {
+                ty = k >> 5;
+                int r = k & 31;
+                tx = r >> 2;
+                c = r & 3;
+                ok = tx < 3 && c < 3;
+            } else {
+                int t = k / cin_tap;
+                c = k - t * cin_tap;
+                ty = t / ks;
+                tx = t - ty * ks;
+                ok = c < Cin;
+            }
+            if (ok) {
+                long long src = (((long long)n * Cin + c) * ks + ty) * ks + tx;
+                v = w[src];
+                if (mask) v *= mask[src];
+            }
+        }
+        wp[idx] = (half_t)v;
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* w, const float* mask, half_t* wp, int Cout, int Cin,
+                                                         int ks, int cout_p, long long total, int ktot) {
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        int c = (int)(idx / ktot);
+        int k = (int)(idx - (long long)c * ktot);
+        int t = k / cout_p;
+        int n = k - t * cout_p;
+        float v = 0.f;
+        if (c < Cin && n < Cout) {
+            int ty = t / ks, tx = t - ty * ks;
+            long long src = (((long long)n * Cin + c) * ks + (ks - 1 - ty)) * ks + (ks - 1 - tx);
+            v = w[src];
+            if (mask) v *= mask[src];
+        }
+        wp[idx] = (half_t)v;
+    }
+}
+
+extern "C" int mcamd_pack_weights(const mcamd_conv_geom* g, const float* w_oihw, const float* mask_oihw, void* wp_fwd,
+                                  void* wp_dgrad, void* stream) {
+    if (check_geom(g, "pack_weights")) return MCAMD_EINVAL;
+    MCAMD_REQUIRE(w_oihw, "pack_weights: null weights");
+    hipStream_t st = (hipStream_t)stream;
+    if (wp_fwd) {
+        int ktot = ntaps_of(g) * cin_tap_of(g);
+        long long total = mcamd_packed_elems_fwd(g);
+        long long grid = (total + 256 * 4 - 1) / (256 * 4);
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(pack_fwd_kernel, dim3((int)grid), dim3(256), 0, st, w_oihw, mask_oihw, (half_t*)wp_fwd, g->cout,
+                           g->cin, g->ksize, cin_tap_of(g), g->stem, total, ktot);
+    }
+    if (wp_dgrad) {
+        MCAMD_REQUIRE(!g->stem, "pack_weights: the stem layer has no dgrad packing");
+        int ktot = g->ksize * g->ksize * cout_p_of(g);
+        long long total = mcamd_packed_elems_dgrad(g);
+        long long grid = (total + 256 * 4 - 1) / (256 * 4);
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(pack_dgrad_kernel, dim3((int)grid), dim3(256), 0, st, w_oihw, mask_oihw, (half_t*)wp_dgrad,
+                           g->cout, g->cin, g->ksize, cout_p_of(g), total, ktot);
+    }
+    MCAMD_LAUNCH_CHECK("pack_weights");
+    return MCAMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// forward / dgrad
+// ---------------------------------------------------------------------------------------
+static int fill_epilogue(IgemmArgs& a, const mcamd_conv_epilogue* e, int n_out, long long M, int cin_tap,
+                         const char* what) {
+    MCAMD_REQUIRE(e && e->y, "%s: null output", what);
+    a.y = e->y;
+    a.mode = e->mode;
+    a.bias = nullptr;
+    a.stats = nullptr;
+    a.scale = nullptr;
+    a.shift = nullptr;
+    a.slope = 1.f;
+    a.y_ld = e->y_ld;
+    a.y_choff = e->y_choff;
+    a.stats_ld = 0;
+    if (e->mode == MCAMD_EPI_NCHW_F32) {
+        a.bias = e->bias;
+    } else if (e->mode == MCAMD_EPI_RAW_F16 || e->mode == MCAMD_EPI_PAD_F16) {
+        MCAMD_REQUIRE(n_out % 8 == 0, "%s: fp16 output needs a channel count that is a multiple of 8 (got %d)", what, n_out);
+        MCAMD_REQUIRE(e->y_ld % 8 == 0 && e->y_choff % 8 == 0 && e->y_choff + n_out <= e->y_ld,
+                      "%s: output slice [%d, %d) does not fit y_ld %d", what, e->y_choff, e->y_choff + n_out, e->y_ld);
+        if (e->mode == MCAMD_EPI_RAW_F16 && e->stats) {
+            int rows = mcamd_igemm_rows(M, n_out, cin_tap);
+            MCAMD_REQUIRE(e->stats_rows == rows, "%s: stats_rows must be mcamd_conv_stats_rows() = %d (got %d)", what, rows,
+                          e->stats_rows);
+            MCAMD_REQUIRE(e->stats_ld >= round_up_int(n_out, 128), "%s: stats_ld must be >= %d", what,
+                          round_up_int(n_out, 128));
+            a.stats = e->stats;
+            a.stats_ld = e->stats_ld;
+        }
+        if (e->mode == MCAMD_EPI_PAD_F16) {
+            a.scale = e->scale;
+            a.shift = e->shift;
+            a.slope = e->slope;
+        }
+    } else {
+        MCAMD_REQUIRE(false, "%s: bad epilogue mode %d", what, e->mode);
+    }
+    return MCAMD_OK;
+}
+
+extern "C" int32_t mcamd_conv_stats_rows(const mcamd_conv_geom* g) {
+    if (!g) return 0;
+    return mcamd_igemm_rows((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g));
+}
+
+extern "C" int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const void* wp_fwd, const mcamd_conv_epilogue* epi,
+                              void* stream) {
+    if (check_geom(g, "conv_fwd")) return MCAMD_EINVAL;
+    MCAMD_REQUIRE(x && wp_fwd, "conv_fwd: null input");
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = (const half_t*)x;
+    a.w = (const half_t*)wp_fwd;
+    a.x_ld = g->x_ld;
+    a.x_row_stride = (g->W + 2) * g->x_ld;
+    a.x_img_stride = (long long)(g->H + 2) * a.x_row_stride;
+    a.x_off = g->x_choff;
+    a.H = g->H, a.W = g->W, a.HW = g->H * g->W;
+    a.M = g->B * g->H * g->W;
+    a.N = g->cout;
+    a.cin_tap = cin_tap_of(g);
+    a.ntaps = ntaps_of(g);
+    a.ktot = a.ntaps * a.cin_tap;
+    fill_taps(g->ksize, g->stem, a.x_row_stride, g->x_ld, a.tap_off);
+    if (fill_epilogue(a, epi, g->cout, a.M, a.cin_tap, "conv_fwd")) return MCAMD_EINVAL;
+    return mcamd_igemm_launch(a, (hipStream_t)stream);
+}
+
+extern "C" int mcamd_conv_dgrad(const mcamd_conv_geom* g, const void* dy, int32_t dy_ld, int32_t dy_choff,
+                                const void* wp_dgrad, const mcamd_conv_epilogue* epi, void* stream) {
+    if (check_geom(g, "conv_dgrad")) return MCAMD_EINVAL;
+    MCAMD_REQUIRE(!g->stem, "conv_dgrad: the stem layer has no input gradient");
+    MCAMD_REQUIRE(dy && wp_dgrad, "conv_dgrad: null input");
+    int cout_p = cout_p_of(g);
+    MCAMD_REQUIRE(dy_ld % 8 == 0 && dy_choff % 8 == 0 && dy_choff + cout_p <= dy_ld,
+                  "conv_dgrad: dy slice [%d, %d) does not fit dy_ld %d", dy_choff, dy_choff + cout_p, dy_ld);
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = (const half_t*)dy;
+    a.w = (const half_t*)wp_dgrad;
+    a.x_ld = dy_ld;
+    a.x_row_stride = (g->W + 2) * dy_ld;
+    a.x_img_stride = (long long)(g->H + 2) * a.x_row_stride;
+    a.x_off = dy_choff;
+    a.H = g->H, a.W = g->W, a.HW = g->H * g->W;
+    a.M = g->B * g->H * g->W;
+    a.N = g->cin;
+    a.cin_tap = cout_p;
+    a.ntaps = g->ksize * g->ksize;
+    a.ktot = a.ntaps * a.cin_tap;
+    fill_taps(g->ksize, 0, a.x_row_stride, dy_ld, a.tap_off);
+    MCAMD_REQUIRE(epi && epi->mode != MCAMD_EPI_PAD_F16 && !epi->stats, "conv_dgrad: epilogue must be mode 0 (no stats) or 1");
+    if (fill_epilogue(a, epi, g->cin, a.M, a.cin_tap, "conv_dgrad")) return MCAMD_EINVAL;
+    return mcamd_igemm_launch(a, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------
+// wgrad
+// ---------------------------------------------------------------------------------------
+extern "C" size_t mcamd_conv_wgrad_workspace_bytes(const mcamd_conv_geom* g) {
+    if (!g) return 0;
+    WgradPlan p = mcamd_wgrad_plan((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g), ntaps_of(g));
+    return p.bytes;
+}
+
+extern "C" int mcamd_conv_wgrad(const mcamd_conv_geom* g, const void* x, const void* dy, int32_t dy_ld, int32_t dy_choff,
+                                const float* mask_oihw, const int32_t* filter_keep, float grad_scale, float* dw_oihw,
+                                float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+    if (check_geom(g, "conv_wgrad")) return MCAMD_EINVAL;
+    MCAMD_REQUIRE(x && dy && dw_oihw && workspace, "conv_wgrad: null argument");
+    MCAMD_REQUIRE(grad_scale > 0.f, "conv_wgrad: grad_scale must be positive");
+    (void)filter_keep;  // reserved: zero filters are already exact through the mask multiply
+    const int cin_tap = cin_tap_of(g), ntaps = ntaps_of(g);
+    const long long M = (long long)g->B * g->H * g->W;
+    WgradPlan p = mcamd_wgrad_plan(M, g->cout, cin_tap, ntaps);
+    MCAMD_REQUIRE(dy_ld % 8 == 0 && dy_choff % 8 == 0 && dy_choff + p.rows_pad <= dy_ld,
+                  "conv_wgrad: dy slice [%d, %d) does not fit dy_ld %d", dy_choff, dy_choff + p.rows_pad, dy_ld);
+    if (workspace_bytes < p.bytes) {
+        mcamd_set_error("conv_wgrad: workspace %zu < %zu bytes", workspace_bytes, p.bytes);
+        return MCAMD_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = (const half_t*)x;
+    a.dy = (const half_t*)dy;
+    a.slab = (float*)workspace;
+    a.x_ld = g->x_ld;
+    a.x_row_stride = (g->W + 2) * g->x_ld;
+    a.x_img_stride = (long long)(g->H + 2) * a.x_row_stride;
+    a.x_off = g->x_choff;
+    a.dy_ld = dy_ld;
+    a.dy_row_stride = (g->W + 2) * dy_ld;
+    a.dy_img_stride = (long long)(g->H + 2) * a.dy_row_stride;
+    a.dy_off = dy_choff + a.dy_row_stride + dy_ld;
+    a.dy_zero_off = dy_choff;
+    a.H = g->H, a.W = g->W, a.HW = g->H * g->W;
+    a.M = (int)M;
+    a.cin_tap = cin_tap;
+    a.ntaps = ntaps;
+    a.ktot = ntaps * cin_tap;
+    fill_taps(g->ksize, g->stem, a.x_row_stride, g->x_ld, a.tap_off);
+    int rc = mcamd_wgrad_launch(a, p, st);
+    if (rc) return rc;
+    rc = mcamd_wgrad_finish_launch((const float*)workspace, p, a.ktot, cin_tap, g->stem, g->cout, g->cin, g->ksize,
+                                   mask_oihw, 1.0f / grad_scale, dw_oihw, st);
+    if (rc) return rc;
+    if (dbias) {
+        long long rows = (long long)g->B * (g->H + 2) * (g->W + 2);
+        rc = mcamd_colsum_launch((const half_t*)dy, rows, dy_ld, dy_choff, g->cout, 1.0f / grad_scale, dbias, st);
+    }
+    return rc;
+}

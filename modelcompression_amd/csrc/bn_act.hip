@@ -1,0 +1,457 @@
+// BatchNorm2d + LeakyReLU + MaxPool2d(2,2) / Reorg(2) / route, fused around the conv kernels.
+// HBM-bound streaming kernels: 16 bytes (8 fp16 channels) per lane, channel-fastest thread
+// mapping so every wave touches whole contiguous pixel rows.
+//
+// Reference ops replaced: nn.BatchNorm2d (nets.py:802, torch defaults eps 1e-5 / momentum 0.1),
+// nn.LeakyReLU(0.1) (nets.py:809), nn.MaxPool2d(2,2) (nets.py:821), Reorg (nets.py:648-667),
+// torch.cat route (nets.py:738-746), and their autograd backward.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------
+// batch statistics -> affine coefficients
+// ------------------------------------------------------------------------------------
+__global__ void bn_coeffs_kernel(const float* stats, int rows, int ld, int C, double count, const float* gamma,
+                                 const float* beta, float* rmean, float* rvar, float momentum, float eps, int training,
+                                 float* scale, float* shift, float* save_mean, float* save_invstd) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double mean, var;
+    if (training) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int p = 0; p < rows; ++p) {
+            s1 += (double)stats[((long long)p * 2 + 0) * ld + c];
+            s2 += (double)stats[((long long)p * 2 + 1) * ld + c];
+        }
+        mean = s1 / count;
+        var = s2 / count - mean * mean;  // biased variance (normalisation)
+        if (var < 0.0) var = 0.0;
+        double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + (double)momentum * mean);
+        rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + (double)momentum * unbiased);
+    } else {
+        mean = rmean[c];
+        var = rvar[c];
+    }
+    double invstd = 1.0 / sqrt(var + (double)eps);
+    float sc = (float)((double)gamma[c] * invstd);
+    scale[c] = sc;
+    shift[c] = (float)((double)beta[c] - mean * (double)sc);
+    if (save_mean) save_mean[c] = (float)mean;
+    if (save_invstd) save_invstd[c] = (float)invstd;
+}
+
+// ------------------------------------------------------------------------------------
+// forward: y(raw fp16) -> leaky(y*scale+shift) -> {plain | 2x2 max pool | reorg} -> padded NHWC
+// ------------------------------------------------------------------------------------
+struct ActArgs {
+    const half_t* y;
+    const float* scale;
+    const float* shift;
+    half_t* dst;
+    half_t* dst2;
+    int B, H, W, C;
+    int y_ld, y_choff, dst_ld, dst_choff, dst2_ld, dst2_choff;
+    float slope;
+    long long items;
+};
+
+__device__ __forceinline__ void load8(const half_t* p, float* v) {
+    h8_t h = *(const h8_t*)p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
+}
+__device__ __forceinline__ void store8(half_t* p, const float* v) {
+    h8_t h;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = (half_t)v[i];
+    *(h8_t*)p = h;
+}
+__device__ __forceinline__ void loadf8(const float* p, float* v) {
+    f32x4_t a = *(const f32x4_t*)p, b = *(const f32x4_t*)(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[i] = a[i];
+        v[4 + i] = b[i];
+    }
+}
+__device__ __forceinline__ long long pad_off(int b, int h, int w, int H, int W, int ld) {
+    return (((long long)b * (H + 2) + h + 1) * (W + 2) + w + 1) * ld;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(ActArgs a) {
+    const int CH = a.C >> 3;
+    const int c8 = (threadIdx.x % CH) * 8;  // fixed per thread: 256 % CH == 0 and the stride is a multiple of 256
+    float sc[8], sh[8];
+    loadf8(a.scale + c8, sc);
+    loadf8(a.shift + c8, sh);
+    const int Ho = a.H >> 1, Wo = a.W >> 1;
+    for (long long item = (long long)blockIdx.x * 256 + threadIdx.x; item < a.items; item += (long long)gridDim.x * 256) {
+        long long pix = item / CH;
+        if (MODE == MCAMD_DST_PLAIN) {
+            int b = (int)(pix / (a.H * a.W));
+            int rem = (int)(pix - (long long)b * a.H * a.W);
+            int h = rem / a.W, w = rem - h * a.W;
+            float v[8];
+            load8(a.y + pix * a.y_ld + a.y_choff + c8, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float z = v[i] * sc[i] + sh[i];
+                v[i] = z > 0.f ? z : z * a.slope;
+            }
+            store8(a.dst + pad_off(b, h, w, a.H, a.W, a.dst_ld) + a.dst_choff + c8, v);
+        } else {
+            int b = (int)(pix / (Ho * Wo));
+            int rem = (int)(pix - (long long)b * Ho * Wo);
+            int ho = rem / Wo, wo = rem - ho * Wo;
+            float act[4][8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int h = 2 * ho + (k >> 1), w = 2 * wo + (k & 1);
+                long long sp = ((long long)b * a.H + h) * a.W + w;
+                load8(a.y + sp * a.y_ld + a.y_choff + c8, act[k]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float z = act[k][i] * sc[i] + sh[i];
+                    act[k][i] = z > 0.f ? z : z * a.slope;
+                }
+                if (a.dst2) store8(a.dst2 + pad_off(b, h, w, a.H, a.W, a.dst2_ld) + a.dst2_choff + c8, act[k]);
+            }
+            long long dp = pad_off(b, ho, wo, Ho, Wo, a.dst_ld) + a.dst_choff;
+            if (MODE == MCAMD_DST_POOL) {
+                float m[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) m[i] = fmaxf(fmaxf(act[0][i], act[1][i]), fmaxf(act[2][i], act[3][i]));
+                store8(a.dst + dp + c8, m);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) store8(a.dst + dp + k * a.C + c8, act[k]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------
+struct ActBwdArgs {
+    const half_t* y;
+    const float* scale;
+    const float* shift;
+    const float* mean;
+    const float* invstd;
+    const half_t* g;
+    const half_t* g2;
+    half_t* dy;
+    float* slab;         // [nblocks][2][C]
+    const float* coef;   // [2][C]: c1 = sum(gz)/count, c2 = sum(gz*xhat)/count
+    int B, H, W, C;
+    int y_ld, y_choff, g_ld, g_choff, g2_ld, g2_choff, dy_ld, dy_choff;
+    float slope;
+    long long items;
+};
+
+// PHASE 0: per-channel sums of g_z and g_z*xhat -> slab.  PHASE 1: dy -> padded NHWC.
+template <int MODE, int PHASE>
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(ActBwdArgs a) {
+    constexpr int NP = MODE == MCAMD_DST_PLAIN ? 1 : 4;
+    const int CH = a.C >> 3;
+    const int c8 = (threadIdx.x % CH) * 8;
+    float sc[8], sh[8], mu[8], is[8], c1[8], c2[8];
+    loadf8(a.scale + c8, sc);
+    loadf8(a.shift + c8, sh);
+    loadf8(a.mean + c8, mu);
+    loadf8(a.invstd + c8, is);
+    if (PHASE == 1) {
+        loadf8(a.coef + c8, c1);
+        loadf8(a.coef + a.C + c8, c2);
+    }
+    float sb[8], sg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sb[i] = sg[i] = 0.f;
+    const int Ho = a.H >> 1, Wo = a.W >> 1;
+
+    for (long long item = (long long)blockIdx.x * 256 + threadIdx.x; item < a.items; item += (long long)gridDim.x * 256) {
+        long long pix = item / CH;
+        int b, hh[NP], ww[NP];
+        long long gp;  // pixel index into g
+        if (MODE == MCAMD_DST_PLAIN) {
+            b = (int)(pix / (a.H * a.W));
+            int rem = (int)(pix - (long long)b * a.H * a.W);
+            hh[0] = rem / a.W;
+            ww[0] = rem - hh[0] * a.W;
+            gp = pix;
+        } else {
+            b = (int)(pix / (Ho * Wo));
+            int rem = (int)(pix - (long long)b * Ho * Wo);
+            int ho = rem / Wo, wo = rem - ho * Wo;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                hh[k] = 2 * ho + (k >> 1);
+                ww[k] = 2 * wo + (k & 1);
+            }
+            gp = pix;
+        }
+        float yv[NP][8], zz[NP][8];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            long long sp = ((long long)b * a.H + hh[k]) * a.W + ww[k];
+            load8(a.y + sp * a.y_ld + a.y_choff + c8, yv[k]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) zz[k][i] = yv[k][i] * sc[i] + sh[i];
+        }
+        float ga[NP][8];
+        if (MODE == MCAMD_DST_PLAIN) {
+            load8(a.g + gp * a.g_ld + a.g_choff + c8, ga[0]);
+        } else if (MODE == MCAMD_DST_POOL) {
+            float gv[8];
+            load8(a.g + gp * a.g_ld + a.g_choff + c8, gv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                // argmax of the activation over the window, first maximum in (h, w) scan order
+                float best = zz[0][i] > 0.f ? zz[0][i] : zz[0][i] * a.slope;
+                int arg = 0;
+#pragma unroll
+                for (int k = 1; k < NP; ++k) {
+                    float av = zz[k][i] > 0.f ? zz[k][i] : zz[k][i] * a.slope;
+                    if (av > best) {
+                        best = av;
+                        arg = k;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NP; ++k) ga[k][i] = (k == arg) ? gv[i] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) load8(a.g + gp * a.g_ld + a.g_choff + k * a.C + c8, ga[k]);
+        }
+        if (a.g2) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                long long sp = ((long long)b * a.H + hh[k]) * a.W + ww[k];
+                float t[8];
+                load8(a.g2 + sp * a.g2_ld + a.g2_choff + c8, t);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ga[k][i] += t[i];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            float out[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float gz = zz[k][i] > 0.f ? ga[k][i] : ga[k][i] * a.slope;
+                float xh = (yv[k][i] - mu[i]) * is[i];
+                if (PHASE == 0) {
+                    sb[i] += gz;
+                    sg[i] += gz * xh;
+                } else {
+                    out[i] = sc[i] * (gz - c1[i] - xh * c2[i]);
+                }
+            }
+            if (PHASE == 1) store8(a.dy + pad_off(b, hh[k], ww[k], a.H, a.W, a.dy_ld) + a.dy_choff + c8, out);
+        }
+    }
+
+    if (PHASE == 0) {
+        __shared__ float red[256 * 16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            red[threadIdx.x * 16 + i] = sb[i];
+            red[threadIdx.x * 16 + 8 + i] = sg[i];
+        }
+        __syncthreads();
+        const int reps = 256 / CH;
+        for (int o = threadIdx.x; o < 16 * CH; o += 256) {
+            int ch = o % CH, v = o / CH;
+            float s = 0.f;
+            for (int k = 0; k < reps; ++k) s += red[(k * CH + ch) * 16 + v];
+            a.slab[((long long)blockIdx.x * 2 + (v >> 3)) * a.C + ch * 8 + (v & 7)] = s;
+        }
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* slab, int nblocks, int C, double count, float inv_scale,
+                                       float* dgamma, float* dbeta, float* coef) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double sb = 0.0, sg = 0.0;
+    for (int p = 0; p < nblocks; ++p) {
+        sb += (double)slab[((long long)p * 2 + 0) * C + c];
+        sg += (double)slab[((long long)p * 2 + 1) * C + c];
+    }
+    if (dbeta) dbeta[c] = (float)(sb * inv_scale);
+    if (dgamma) dgamma[c] = (float)(sg * inv_scale);
+    coef[c] = (float)(sb / count);
+    coef[C + c] = (float)(sg / count);
+}
+
+// ------------------------------------------------------------------------------------
+// NCHW fp32 -> padded NHWC fp16 (model boundary)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, int B, int C, int H, int W, float mul,
+                                                           half_t* dst, int ld, int choff, int cgroups) {
+    // item = (pixel, channel group of up to 8); consecutive threads -> consecutive pixels (coalesced NCHW reads)
+    const long long HW = (long long)H * W;
+    const long long items = (long long)B * HW * cgroups;
+    for (long long item = (long long)blockIdx.x * 256 + threadIdx.x; item < items; item += (long long)gridDim.x * 256) {
+        long long pg = item / ((long long)B * HW);  // channel group slowest
+        long long pix = item - pg * (long long)B * HW;
+        int b = (int)(pix / HW);
+        int rem = (int)(pix - (long long)b * HW);
+        int h = rem / W, w = rem - h * W;
+        int c0 = (int)pg * 8;
+        half_t* d = dst + pad_off(b, h, w, H, W, ld) + choff + c0;
+        const float* s = src + ((long long)b * C + c0) * HW + rem;
+        int nc = C - c0 < 8 ? C - c0 : 8;
+        if (ld == 4) {  // stem image: 3 channels + one zero, one 8-byte store per pixel
+            h4_t q;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i] = (i < nc) ? (half_t)(s[i * HW] * mul) : (half_t)0.f;
+            *(h4_t*)d = q;
+        } else if (nc == 8) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = s[i * HW] * mul;
+            store8(d, v);
+        } else {
+            for (int i = 0; i < nc; ++i) d[i] = (half_t)(s[i * HW] * mul);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------
+static int stream_grid(long long items) {
+    long long g = (items + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int mcamd_bn_coeffs(const float* stats, int32_t stats_rows, int32_t stats_ld, int32_t C, int64_t count,
+                               const float* gamma, const float* beta, float* running_mean, float* running_var,
+                               float momentum, float eps, int32_t training, float* scale, float* shift,
+                               float* save_mean, float* save_invstd, void* stream) {
+    MCAMD_REQUIRE(C > 0 && gamma && beta && running_mean && running_var && scale && shift, "bn_coeffs: null argument");
+    MCAMD_REQUIRE(!training || (stats && stats_rows > 0 && stats_ld >= C && count > 0), "bn_coeffs: bad statistics slab");
+    hipLaunchKernelGGL(bn_coeffs_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, stats_rows,
+                       stats_ld, C, (double)count, gamma, beta, running_mean, running_var, momentum, eps, training,
+                       scale, shift, save_mean, save_invstd);
+    MCAMD_LAUNCH_CHECK("bn_coeffs");
+    return MCAMD_OK;
+}
+
+static int check_c(int C, const char* what) {
+    int CH = C / 8;
+    if (C <= 0 || C % 8 != 0 || CH > 256 || 256 % CH != 0) {
+        mcamd_set_error("%s: channel count %d must be 8 * (a power of two <= 256)", what, C);
+        return MCAMD_EINVAL;
+    }
+    return MCAMD_OK;
+}
+
+extern "C" int mcamd_bn_act_fwd(const mcamd_act_desc* d, void* stream) {
+    MCAMD_REQUIRE(d && d->y && d->dst && d->scale && d->shift, "bn_act_fwd: null argument");
+    if (check_c(d->C, "bn_act_fwd")) return MCAMD_EINVAL;
+    MCAMD_REQUIRE(d->y_ld % 8 == 0 && d->y_choff % 8 == 0 && d->dst_ld % 8 == 0 && d->dst_choff % 8 == 0 &&
+                      d->dst2_ld % 8 == 0 && d->dst2_choff % 8 == 0,
+                  "bn_act_fwd: leading dimensions / channel offsets must be multiples of 8");
+    MCAMD_REQUIRE(d->mode == MCAMD_DST_PLAIN || (d->H % 2 == 0 && d->W % 2 == 0), "bn_act_fwd: pool/reorg need even H, W");
+    MCAMD_REQUIRE(d->mode != MCAMD_DST_PLAIN || !d->dst2, "bn_act_fwd: dst2 only with pool/reorg");
+    ActArgs a;
+    a.y = (const half_t*)d->y;
+    a.scale = d->scale;
+    a.shift = d->shift;
+    a.dst = (half_t*)d->dst;
+    a.dst2 = (half_t*)d->dst2;
+    a.B = d->B, a.H = d->H, a.W = d->W, a.C = d->C;
+    a.y_ld = d->y_ld, a.y_choff = d->y_choff, a.dst_ld = d->dst_ld, a.dst_choff = d->dst_choff;
+    a.dst2_ld = d->dst2_ld, a.dst2_choff = d->dst2_choff;
+    a.slope = d->slope;
+    long long pixels = (long long)d->B * d->H * d->W;
+    if (d->mode != MCAMD_DST_PLAIN) pixels /= 4;
+    a.items = pixels * (d->C / 8);
+    int grid = stream_grid(a.items);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->mode == MCAMD_DST_PLAIN) hipLaunchKernelGGL(bn_act_fwd_kernel<MCAMD_DST_PLAIN>, dim3(grid), dim3(256), 0, st, a);
+    else if (d->mode == MCAMD_DST_POOL) hipLaunchKernelGGL(bn_act_fwd_kernel<MCAMD_DST_POOL>, dim3(grid), dim3(256), 0, st, a);
+    else if (d->mode == MCAMD_DST_REORG) hipLaunchKernelGGL(bn_act_fwd_kernel<MCAMD_DST_REORG>, dim3(grid), dim3(256), 0, st, a);
+    else MCAMD_REQUIRE(false, "bn_act_fwd: bad mode %d", d->mode);
+    MCAMD_LAUNCH_CHECK("bn_act_fwd");
+    return MCAMD_OK;
+}
+
+static const int kBwdBlocks = 1024;
+
+extern "C" size_t mcamd_bn_act_bwd_workspace_bytes(const mcamd_act_bwd_desc* d) {
+    return ((size_t)kBwdBlocks * 2 * d->C + 2 * (size_t)d->C) * sizeof(float);
+}
+
+extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+    MCAMD_REQUIRE(d && d->y && d->g && d->dy && d->scale && d->shift && d->mean && d->invstd && workspace,
+                  "bn_act_bwd: null argument");
+    if (check_c(d->C, "bn_act_bwd")) return MCAMD_EINVAL;
+    if (workspace_bytes < mcamd_bn_act_bwd_workspace_bytes(d)) {
+        mcamd_set_error("bn_act_bwd: workspace %zu < %zu bytes", workspace_bytes, mcamd_bn_act_bwd_workspace_bytes(d));
+        return MCAMD_EWORKSPACE;
+    }
+    MCAMD_REQUIRE(d->y_ld % 8 == 0 && d->y_choff % 8 == 0 && d->g_ld % 8 == 0 && d->g_choff % 8 == 0 &&
+                      d->g2_ld % 8 == 0 && d->g2_choff % 8 == 0 && d->dy_ld % 8 == 0 && d->dy_choff % 8 == 0,
+                  "bn_act_bwd: leading dimensions / channel offsets must be multiples of 8");
+    MCAMD_REQUIRE(d->mode == MCAMD_DST_PLAIN || (d->H % 2 == 0 && d->W % 2 == 0), "bn_act_bwd: pool/reorg need even H, W");
+    MCAMD_REQUIRE(d->grad_scale > 0.f, "bn_act_bwd: grad_scale must be positive");
+    ActBwdArgs a;
+    a.y = (const half_t*)d->y;
+    a.scale = d->scale, a.shift = d->shift, a.mean = d->mean, a.invstd = d->invstd;
+    a.g = (const half_t*)d->g;
+    a.g2 = (const half_t*)d->g2;
+    a.dy = (half_t*)d->dy;
+    a.slab = (float*)workspace;
+    float* coef = (float*)workspace + (size_t)kBwdBlocks * 2 * d->C;
+    a.coef = coef;
+    a.B = d->B, a.H = d->H, a.W = d->W, a.C = d->C;
+    a.y_ld = d->y_ld, a.y_choff = d->y_choff, a.g_ld = d->g_ld, a.g_choff = d->g_choff;
+    a.g2_ld = d->g2_ld, a.g2_choff = d->g2_choff, a.dy_ld = d->dy_ld, a.dy_choff = d->dy_choff;
+    a.slope = d->slope;
+    long long pixels = (long long)d->B * d->H * d->W;
+    double count = (double)pixels;
+    if (d->mode != MCAMD_DST_PLAIN) pixels /= 4;
+    a.items = pixels * (d->C / 8);
+    int grid = stream_grid(a.items);
+    if (grid > kBwdBlocks) grid = kBwdBlocks;
+    hipStream_t st = (hipStream_t)stream;
+#define BWD_LAUNCH(PHASE)                                                                                         \
+    if (d->mode == MCAMD_DST_PLAIN)                                                                               \
+        hipLaunchKernelGGL((bn_act_bwd_kernel<MCAMD_DST_PLAIN, PHASE>), dim3(grid), dim3(256), 0, st, a);         \
+    else if (d->mode == MCAMD_DST_POOL)                                                                           \
+        hipLaunchKernelGGL((bn_act_bwd_kernel<MCAMD_DST_POOL, PHASE>), dim3(grid), dim3(256), 0, st, a);          \
+    else if (d->mode == MCAMD_DST_REORG)                                                                          \
+        hipLaunchKernelGGL((bn_act_bwd_kernel<MCAMD_DST_REORG, PHASE>), dim3(grid), dim3(256), 0, st, a);         \
+    else                                                                                                          \
+        MCAMD_REQUIRE(false, "bn_act_bwd: bad mode %d", d->mode);
+    BWD_LAUNCH(0)
+    MCAMD_LAUNCH_CHECK("bn_act_bwd reduce");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + 63) / 64), dim3(64), 0, st, (const float*)a.slab, grid, d->C,
+                       count, 1.0f / d->grad_scale, d->dgamma, d->dbeta, coef);
+    MCAMD_LAUNCH_CHECK("bn_act_bwd finalize");
+    BWD_LAUNCH(1)
+    MCAMD_LAUNCH_CHECK("bn_act_bwd apply");
+#undef BWD_LAUNCH
+    return MCAMD_OK;
+}
+
+extern "C" int mcamd_nchw_f32_to_padded_nhwc_f16(const float* src, int32_t B, int32_t C, int32_t H, int32_t W, float mul,
+                                                 void* dst, int32_t dst_ld, int32_t dst_choff, void* stream) {
+    MCAMD_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc: bad argument");
+    MCAMD_REQUIRE(dst_choff + C <= dst_ld || dst_ld == 4, "nchw_to_nhwc: channel slice exceeds ld");
+    MCAMD_REQUIRE((C >= 8) ? (dst_ld % 8 == 0 && dst_choff % 8 == 0) : true, "nchw_to_nhwc: alignment");
+    int cgroups = (C + 7) / 8;
+    long long items = (long long)B * H * W * cgroups;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(stream_grid(items)), dim3(256), 0, (hipStream_t)stream, src, B, C, H, W,
+                       mul, (half_t*)dst, dst_ld, dst_choff, cgroups);
+    MCAMD_LAUNCH_CHECK("nchw_to_nhwc");
+    return MCAMD_OK;
+}

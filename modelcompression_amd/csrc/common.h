@@ -1,0 +1,50 @@
+// Shared device/host helpers for libmcamd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mcamd.h"
+
+typedef _Float16 half_t;
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+#define MCAMD_WAVE 64
+
+void mcamd_set_error(const char* fmt, ...);
+
+#define MCAMD_REQUIRE(cond, ...)            \
+    do {                                    \
+        if (!(cond)) {                      \
+            mcamd_set_error(__VA_ARGS__);   \
+            return MCAMD_EINVAL;            \
+        }                                   \
+    } while (0)
+
+#define MCAMD_LAUNCH_CHECK(what)                                                    \
+    do {                                                                            \
+        hipError_t e_ = hipGetLastError();                                          \
+        if (e_ != hipSuccess) {                                                     \
+            mcamd_set_error("%s: launch failed: %s", what, hipGetErrorString(e_));  \
+            return MCAMD_ELAUNCH;                                                   \
+        }                                                                           \
+    } while (0)
+
+static inline int round_up_int(int v, int m) { return (v + m - 1) / m * m; }
+static inline long long round_up_ll(long long v, long long m) { return (v + m - 1) / m * m; }
+
+// Row r of a 32x32 MFMA accumulator fragment held by `lane` in register `reg`
+// (cdna_hip_programming.md section 3: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)).
+__device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// 16-byte async copy global -> LDS (global_load_lds_dwordx4).  The LDS address must be
+// wave-uniform; lane i lands at lds + 16*i.  The global address is per lane.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}

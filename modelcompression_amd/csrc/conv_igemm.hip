@@ -1,0 +1,317 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): forward and dgrad.
+//
+//   D[m][n] = sum_{tap, c} X[pixel(m) + tap][c] * Wp[n][tap*cin + c]
+//
+// m enumerates the B*H*W real output pixels, n the output channels.  X is a padded NHWC
+// fp16 activation (zero halo), so every tap address is in bounds and no im2col buffer or
+// bounds test exists: one K-chunk of the A tile is BM rows of BK contiguous halfs, fetched
+// by per-lane-addressed global_load_lds_dwordx4 straight into LDS (never through VGPRs).
+// Wp is the packed fp16 weight matrix [Npad][K], K contiguous, so the B tile has the same
+// shape.  dgrad is the same kernel run on the padded dY with the flipped/transposed packing.
+//
+// Tile: BM x BN per workgroup, (BM/WM) x (BN/WN) waves, each wave WM x WN built from
+// 32x32x16 f16 MFMAs (fp32 accumulate).  LDS rows are BK halfs (64 or 128 bytes) with the
+// 16-byte chunks XOR-swizzled so the ds_read_b128 fragment reads are bank-conflict free; the
+// swizzle is applied on the DMA *source* address because the DMA writes LDS lane-linearly.
+// Two LDS stages; the DMA for chunk q+1 is in flight while chunk q is multiplied.
+// Workgroups are persistent over M tiles (grid.x) for one N tile (grid.y) so that BatchNorm
+// partial sums are accumulated in registers and written once per workgroup (deterministic).
+//
+// Replaces F.conv2d at reference src/pruning/weightPruning/layers.py:60-64 and its autograd
+// input gradient.
+#include "kernels.h"
+#include <stdlib.h>
+
+
+template <int CPR>
+__device__ __forceinline__ int swz(int row) {
+    // CPR = 16-byte chunks per LDS row.  64-byte rows: 4 rows span the 64 banks -> XOR with
+    // (row>>2)&3; 128-byte rows: 2 rows span them -> XOR with (row>>1)&7.  Either makes the 16
+    // lanes of every ds_read_b128 lane group hit 16 distinct 16-byte slots.
+    return CPR == 4 ? ((row >> 2) & 3) : ((row >> 1) & 7);
+}
+
+template <int BM, int BN, int WM, int WN, int BK>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BN >= 128 ? 2 : (BN >= 64 ? 3 : 4))) void igemm_kernel(IgemmArgs a) {
+    constexpr int WAVES_N = BN / WN;
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    constexpr int CPR = BK / 8;
+    constexpr int A_SLOTS = BM * CPR, B_SLOTS = BN * CPR;
+    constexpr int A_IT = (A_SLOTS + NT - 1) / NT, B_IT = (B_SLOTS + NT - 1) / NT;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int STAGE_BYTES = (A_SLOTS + B_SLOTS) * 16;
+    static_assert(A_SLOTS % 64 == 0 && B_SLOTS % 64 == 0, "whole waves per DMA instruction");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int nt = blockIdx.y;
+    const int nchunks = a.ktot / BK;
+    const int cpt = a.cin_tap / BK;  // chunks per tap
+
+    // B (weight) row bases are the same for every M tile.
+    long long bbase[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        int slot = it * NT + tid;
+        int row = slot / CPR, phys = slot % CPR;
+        int logical = phys ^ swz<CPR>(row);
+        bbase[it] = (long long)(nt * BN + row) * a.ktot + logical * 8;
+    }
+
+    float s1[TN], s2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
+
+    for (int mt = blockIdx.x; mt < a.num_mtiles; mt += gridDim.x) {
+        // ---- per-tile A row bases (top-left tap of each output pixel, swizzled chunk) ----
+        long long abase[A_IT];
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            int slot = it * NT + tid;
+            int row = slot / CPR, phys = slot % CPR;
+            int logical = phys ^ swz<CPR>(row);
+            int m = mt * BM + row;
+            if (m > a.M - 1) m = a.M - 1;  // tail rows re-read the last pixel; their results are masked
+            int b = m / a.HW;
+            int rem = m - b * a.HW;
+            int h = rem / a.W;
+            int w = rem - h * a.W;
+            abase[it] = (long long)b * a.x_img_stride + (long long)h * a.x_row_stride + (long long)w * a.x_ld +
+                        a.x_off + logical * 8;
+        }
+
+        f32x16_t acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        auto stage = [&](int q, int buf) {
+            int tap = q / cpt;
+            int koff = a.tap_off[tap] + (q - tap * cpt) * BK;
+            char* sa = smem + buf * STAGE_BYTES;
+            char* sb = sa + A_SLOTS * 16;
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                int wslot = it * NT + (tid & ~63);
+                if (wslot < A_SLOTS) glds16(a.x + abase[it] + koff, sa + wslot * 16);
+            }
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) {
+                int wslot = it * NT + (tid & ~63);
+                if (wslot < B_SLOTS) glds16(a.w + bbase[it] + (long long)q * BK, sb + wslot * 16);
+            }
+        };
+
+        __syncthreads();  // previous tile's epilogue has finished with the LDS
+        stage(0, 0);
+        for (int q = 0; q < nchunks; ++q) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // chunk q landed for every wave; every wave is done reading chunk q-1
+            if (q + 1 < nchunks) stage(q + 1, (q + 1) & 1);
+            const char* sa = smem + (q & 1) * STAGE_BYTES;
+            const char* sb = sa + A_SLOTS * 16;
+#pragma unroll
+            for (int s = 0; s < BK / 16; ++s) {
+                const int chunk = 2 * s + (lane >> 5);
+                h8_t af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    int row = wm * WM + i * 32 + (lane & 31);
+                    af[i] = *(const h8_t*)(sa + (row * CPR + (chunk ^ swz<CPR>(row))) * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    int row = wn * WN + j * 32 + (lane & 31);
+                    bf[j] = *(const h8_t*)(sb + (row * CPR + (chunk ^ swz<CPR>(row))) * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+
+        // ------------------------------- epilogue -------------------------------
+        if (a.mode == MCAMD_EPI_NCHW_F32) {
+            float* y = (float*)a.y;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int m = mt * BM + wm * WM + i * 32 + mfma32_row(r, lane);
+                    if (m < a.M) {
+                        int b = m / a.HW;
+                        int hw = m - b * a.HW;
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            int n = nt * BN + wn * WN + j * 32 + (lane & 31);
+                            if (n < a.N) {
+                                float v = acc[i][j][r];
+                                if (a.bias) v += a.bias[n];
+                                y[((long long)b * a.N + n) * a.HW + hw] = v;
+                            }
+                        }
+                    }
+                }
+        } else {
+            __syncthreads();  // every wave is done with the stage buffers
+            half_t* ct = (half_t*)smem;  // [BM][BN] fp16 output tile
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = wn * WN + j * 32 + (lane & 31);
+                float sc = 1.f, sh = 0.f;
+                if (a.mode == MCAMD_EPI_PAD_F16) {
+                    int n = nt * BN + col;
+                    if (n < a.N) {
+                        if (a.scale) sc = a.scale[n];
+                        if (a.shift) sh = a.shift[n];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wm * WM + i * 32 + mfma32_row(r, lane);
+                        float v = acc[i][j][r];
+                        if (a.mode == MCAMD_EPI_PAD_F16) {
+                            v = v * sc + sh;
+                            v = v > 0.f ? v : v * a.slope;
+                        }
+                        half_t hv = (half_t)v;
+                        ct[row * BN + col] = hv;
+                        if (a.stats) {
+                            float fv = (mt * BM + row < a.M) ? (float)hv : 0.f;
+                            s1[j] += fv;
+                            s2[j] += fv * fv;
+                        }
+                    }
+            }
+            __syncthreads();
+            constexpr int CH = BN / 8;  // 16-byte chunks per output row
+            half_t* y = (half_t*)a.y;
+            for (int slot = tid; slot < BM * CH; slot += NT) {
+                int row = slot / CH, ch = slot - row * CH;
+                int m = mt * BM + row;
+                int n0 = nt * BN + ch * 8;
+                if (m < a.M && n0 < a.N) {
+                    long long off;
+                    if (a.mode == MCAMD_EPI_PAD_F16) {
+                        int b = m / a.HW;
+                        int rem = m - b * a.HW;
+                        int h = rem / a.W;
+                        int w = rem - h * a.W;
+                        off = (((long long)b * (a.H + 2) + h + 1) * (a.W + 2) + w + 1) * a.y_ld;
+                    } else {
+                        off = (long long)m * a.y_ld;
+                    }
+                    *(h8_t*)(y + off + a.y_choff + n0) = *(const h8_t*)(ct + row * BN + ch * 8);
+                }
+            }
+        }
+    }
+
+    if (a.stats) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            s1[j] += __shfl_xor(s1[j], 32);
+            s2[j] += __shfl_xor(s2[j], 32);
+        }
+        __syncthreads();
+        float* red = (float*)smem;  // [BM/WM][2][BN]
+        if (lane < 32) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                red[(wm * 2 + 0) * BN + wn * WN + j * 32 + lane] = s1[j];
+                red[(wm * 2 + 1) * BN + wn * WN + j * 32 + lane] = s2[j];
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < 2 * BN; t += NT) {
+            int which = t / BN, col = t - which * BN;
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < BM / WM; ++k) v += red[(k * 2 + which) * BN + col];
+            a.stats[((long long)blockIdx.x * 2 + which) * a.stats_ld + nt * BN + col] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+struct TileCfg {
+    int bm, bn, bk;
+};
+
+static int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return s && *s ? atoi(s) : dflt;
+}
+
+static TileCfg pick_tile(int n, int cin_tap) {
+    // N tile: the candidate with the least padding, larger on ties (125 -> 128, 192 -> 64, 32 -> 32).
+    TileCfg t;
+    t.bm = 128;
+    int best = 128, waste = round_up_int(n, 128);
+    for (int bn = 64; bn >= 32; bn /= 2)
+        if (round_up_int(n, bn) < waste) {
+            waste = round_up_int(n, bn);
+            best = bn;
+        }
+    t.bn = best;
+    int want_bk = env_int("MCAMD_BK", 32);
+    t.bk = (want_bk == 64 && cin_tap % 64 == 0) ? 64 : 32;
+    return t;
+}
+
+int mcamd_igemm_mtiles(long long M) { return (int)((M + 127) / 128); }
+
+// Number of persistent workgroups along M (== rows of the BN-statistics slab).
+int mcamd_igemm_rows(long long M, int n, int cin_tap) {
+    TileCfg t = pick_tile(n, cin_tap);
+    int ntiles = (n + t.bn - 1) / t.bn;
+    int mtiles = mcamd_igemm_mtiles(M);
+    int target = env_int("MCAMD_IGEMM_WGS", 2048);
+    int p = target / ntiles;
+    if (p < 1) p = 1;
+    if (p > mtiles) p = mtiles;
+    return p;
+}
+
+template <int BM, int BN, int WM, int WN, int BK>
+static void launch_one(const IgemmArgs& a, int rows, int ntiles, hipStream_t st) {
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    constexpr int STAGE_BYTES = (BM + BN) * (BK / 8) * 16;
+    size_t lds = 2 * STAGE_BYTES;
+    if (lds < (size_t)BM * BN * 2) lds = (size_t)BM * BN * 2;
+    if (lds < (size_t)(BM / WM) * 2 * BN * 4) lds = (size_t)(BM / WM) * 2 * BN * 4;
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BK>), dim3(rows, ntiles), dim3(NT), lds, st, a);
+}
+
+// a.* geometry fields must be filled by the caller; picks the tile and launches.
+int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st) {
+    TileCfg t = pick_tile(a.N, a.cin_tap);
+    if (a.cin_tap % t.bk != 0 || a.ktot % t.bk != 0) {
+        mcamd_set_error("igemm: K per tap (%d) must be a multiple of %d", a.cin_tap, t.bk);
+        return MCAMD_EINVAL;
+    }
+    int ntiles = (a.N + t.bn - 1) / t.bn;
+    a.num_mtiles = mcamd_igemm_mtiles(a.M);
+    int rows = mcamd_igemm_rows(a.M, a.N, a.cin_tap);
+    if (t.bn == 128 && t.bk == 32) launch_one<128, 128, 64, 64, 32>(a, rows, ntiles, st);
+    else if (t.bn == 128) launch_one<128, 128, 64, 64, 64>(a, rows, ntiles, st);
+    else if (t.bn == 64 && t.bk == 32) launch_one<128, 64, 64, 32, 32>(a, rows, ntiles, st);
+    else if (t.bn == 64) launch_one<128, 64, 64, 32, 64>(a, rows, ntiles, st);
+    else if (t.bk == 32) launch_one<128, 32, 32, 32, 32>(a, rows, ntiles, st);
+    else launch_one<128, 32, 32, 32, 64>(a, rows, ntiles, st);
+    MCAMD_LAUNCH_CHECK("igemm");
+    return MCAMD_OK;
+}

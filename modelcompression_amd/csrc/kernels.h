@@ -1,0 +1,60 @@
+// Internal launch descriptors shared between the kernel translation units and api.hip.
+#pragma once
+#include "common.h"
+
+struct IgemmArgs {
+    const half_t* x;
+    const half_t* w;
+    void* y;
+    const float* bias;
+    float* stats;
+    const float* scale;
+    const float* shift;
+    long long x_img_stride;  // elements between images of x
+    int x_row_stride;        // elements between padded rows of x
+    int x_ld;                // elements per pixel of x
+    int x_off;               // channel offset added to every row base
+    int H, W, HW, M, N;
+    int ktot;                // ntaps * cin_tap
+    int cin_tap;
+    int ntaps;
+    int tap_off[9];          // element offset of tap t from the row base
+    int mode;
+    int y_ld, y_choff;
+    int stats_ld;
+    float slope;
+    int num_mtiles;
+};
+
+struct WgradArgs {
+    const half_t* x;
+    const half_t* dy;
+    float* slab;
+    long long x_img_stride, dy_img_stride;
+    int x_row_stride, dy_row_stride, x_ld, dy_ld;
+    int x_off;        // channel offset of x
+    int dy_off;       // channel offset of dy + offset of padded pixel (1,1)
+    int dy_zero_off;  // channel offset of dy at padded pixel (0,0): a zero row
+    int H, W, HW, M;
+    int rows_pad;     // slab rows
+    int ktot, cin_tap, ntaps;
+    int tap_off[9];
+    int n_ctiles;     // cin tiles per tap
+    int pix_per_split;
+};
+
+struct WgradPlan {
+    int tmo, tnc, rows_pad, n_otiles, n_ctiles, nsplit, pix_per_split;
+    size_t bytes;
+};
+
+int mcamd_igemm_mtiles(long long M);
+int mcamd_igemm_rows(long long M, int n, int cin_tap);
+int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st);
+
+WgradPlan mcamd_wgrad_plan(long long M, int cout, int cin_tap, int ntaps);
+int mcamd_wgrad_launch(WgradArgs& a, const WgradPlan& p, hipStream_t st);
+int mcamd_wgrad_finish_launch(const float* slab, const WgradPlan& p, int ktot, int cin_tap, int stem, int Cout, int Cin,
+                              int ksize, const float* mask, float inv_scale, float* dw, hipStream_t st);
+int mcamd_colsum_launch(const half_t* dy, long long rows, int ld, int choff, int C, float inv_scale, float* out,
+                        hipStream_t st);

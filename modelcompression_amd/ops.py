@@ -1,0 +1,228 @@
+"""Thin torch-tensor wrappers over the C-ABI (include/mcamd.h).
+
+Tensors are only containers for device memory here (allocation + stream come
+from PyTorch-ROCm); every compute call goes to libmcamd.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import ConvGeom, ConvEpilogue, ActDesc, ActBwdDesc, check, ptr, stream_ptr
+
+HALF = torch.float16
+SLACK = 64  # fp16 elements of zeroed slack after every activation buffer
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.McamdError("modelcompression_amd compute ops need CUDA (MI355X) tensors; there is no CPU path")
+
+
+def alloc_padded(B, H, W, ld, device):
+    """Zeroed padded-NHWC fp16 buffer [B][H+2][W+2][ld] (+ slack), flat."""
+    return torch.zeros(B * (H + 2) * (W + 2) * ld + SLACK, dtype=HALF, device=device)
+
+
+def padded_view(buf, B, H, W, ld):
+    return buf[: B * (H + 2) * (W + 2) * ld].view(B, H + 2, W + 2, ld)
+
+
+def geom(B, H, W, ksize, cin, cout, x_ld, x_choff=0, stem=0):
+    return ConvGeom(B, H, W, ksize, cin, cout, x_ld, x_choff, stem)
+
+
+def packed_elems(g):
+    lib = L.lib()
+    return int(lib.mcamd_packed_elems_fwd(C.byref(g))), int(lib.mcamd_packed_elems_dgrad(C.byref(g)))
+
+
+def pack_weights(g, w, mask=None, want_fwd=True, want_dgrad=True, out_fwd=None, out_dgrad=None):
+    """fp32 OIHW master (* mask) -> (fwd, dgrad) fp16 packings (layers.py:59 replacement)."""
+    _need_cuda(w, mask)
+    assert w.dtype == torch.float32 and w.is_contiguous()
+    nf, nd = packed_elems(g)
+    if want_fwd and out_fwd is None:
+        out_fwd = torch.empty(nf, dtype=HALF, device=w.device)
+    if want_dgrad and not g.stem and out_dgrad is None:
+        out_dgrad = torch.empty(nd, dtype=HALF, device=w.device)
+    check(L.lib().mcamd_pack_weights(C.byref(g), ptr(w), ptr(mask), ptr(out_fwd) if want_fwd else None,
+                                     ptr(out_dgrad) if (want_dgrad and not g.stem) else None, stream_ptr()),
+          "mcamd_pack_weights")
+    return out_fwd, out_dgrad
+
+
+def stats_rows(g):
+    return int(L.lib().mcamd_conv_stats_rows(C.byref(g)))
+
+
+def _epi(mode, y, y_ld=0, y_choff=0, bias=None, stats=None, stats_rows_=0, stats_ld=0, scale=None, shift=None,
+         slope=1.0):
+    e = ConvEpilogue()
+    e.mode, e.y_ld, e.y_choff = mode, y_ld, y_choff
+    e.y = y.data_ptr()
+    e.bias = bias.data_ptr() if bias is not None else None
+    e.stats = stats.data_ptr() if stats is not None else None
+    e.stats_rows, e.stats_ld = stats_rows_, stats_ld
+    e.scale = scale.data_ptr() if scale is not None else None
+    e.shift = shift.data_ptr() if shift is not None else None
+    e.slope = slope
+    return e
+
+
+def conv_fwd_raw(g, x, wp, y, y_ld, y_choff=0, stats=None):
+    """y[M][y_ld] fp16 raw conv output; `stats`: fp32 [stats_rows(g)][2][stats_ld] slab or None."""
+    e = _epi(L.EPI_RAW_F16, y, y_ld, y_choff, stats=stats,
+             stats_rows_=stats.shape[0] if stats is not None else 0,
+             stats_ld=stats.shape[2] if stats is not None else 0)
+    check(L.lib().mcamd_conv_fwd(C.byref(g), ptr(x), ptr(wp), C.byref(e), stream_ptr()), "mcamd_conv_fwd")
+
+
+def conv_fwd_nchw(g, x, wp, y, bias=None):
+    e = _epi(L.EPI_NCHW_F32, y, bias=bias)
+    check(L.lib().mcamd_conv_fwd(C.byref(g), ptr(x), ptr(wp), C.byref(e), stream_ptr()), "mcamd_conv_fwd")
+
+
+def conv_fwd_padded(g, x, wp, y, y_ld, y_choff=0, scale=None, shift=None, slope=1.0):
+    e = _epi(L.EPI_PAD_F16, y, y_ld, y_choff, scale=scale, shift=shift, slope=slope)
+    check(L.lib().mcamd_conv_fwd(C.byref(g), ptr(x), ptr(wp), C.byref(e), stream_ptr()), "mcamd_conv_fwd")
+
+
+def conv_dgrad_raw(g, dy, dy_ld, dy_choff, wpd, out, out_ld, out_choff=0):
+    e = _epi(L.EPI_RAW_F16, out, out_ld, out_choff)
+    check(L.lib().mcamd_conv_dgrad(C.byref(g), ptr(dy), dy_ld, dy_choff, ptr(wpd), C.byref(e), stream_ptr()),
+          "mcamd_conv_dgrad")
+
+
+def conv_dgrad_nchw(g, dy, dy_ld, dy_choff, wpd, out):
+    e = _epi(L.EPI_NCHW_F32, out)
+    check(L.lib().mcamd_conv_dgrad(C.byref(g), ptr(dy), dy_ld, dy_choff, ptr(wpd), C.byref(e), stream_ptr()),
+          "mcamd_conv_dgrad")
+
+
+def wgrad_workspace_bytes(g):
+    return int(L.lib().mcamd_conv_wgrad_workspace_bytes(C.byref(g)))
+
+
+def conv_wgrad(g, x, dy, dy_ld, dy_choff, dw, mask=None, grad_scale=1.0, dbias=None, workspace=None):
+    if workspace is None:
+        workspace = torch.empty(wgrad_workspace_bytes(g), dtype=torch.uint8, device=dw.device)
+    check(L.lib().mcamd_conv_wgrad(C.byref(g), ptr(x), ptr(dy), dy_ld, dy_choff, ptr(mask), None, grad_scale, ptr(dw),
+                                   ptr(dbias), ptr(workspace), workspace.numel(), stream_ptr()), "mcamd_conv_wgrad")
+
+
+def bn_coeffs(stats, C_, count, gamma, beta, rmean, rvar, training, scale, shift, mean=None, invstd=None,
+              momentum=0.1, eps=1e-5):
+    rows = stats.shape[0] if stats is not None else 0
+    ld = stats.shape[2] if stats is not None else 0
+    check(L.lib().mcamd_bn_coeffs(ptr(stats), rows, ld, C_, count, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
+                                  momentum, eps, 1 if training else 0, ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+                                  stream_ptr()), "mcamd_bn_coeffs")
+
+
+def bn_act_fwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, slope, mode, dst, dst_ld, dst_choff=0, dst2=None,
+               dst2_ld=0, dst2_choff=0):
+    d = ActDesc()
+    d.B, d.H, d.W, d.C = B, H, W, C_
+    d.y, d.y_ld, d.y_choff = y.data_ptr(), y_ld, y_choff
+    d.scale, d.shift, d.slope, d.mode = scale.data_ptr(), shift.data_ptr(), slope, mode
+    d.dst, d.dst_ld, d.dst_choff = dst.data_ptr(), dst_ld, dst_choff
+    d.dst2 = dst2.data_ptr() if dst2 is not None else None
+    d.dst2_ld, d.dst2_choff = dst2_ld, dst2_choff
+    check(L.lib().mcamd_bn_act_fwd(C.byref(d), stream_ptr()), "mcamd_bn_act_fwd")
+
+
+def bn_act_bwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, mean, invstd, slope, mode, g, g_ld, g_choff, dy, dy_ld,
+               dy_choff, dgamma, dbeta, grad_scale=1.0, g2=None, g2_ld=0, g2_choff=0, workspace=None):
+    d = ActBwdDesc()
+    d.B, d.H, d.W, d.C = B, H, W, C_
+    d.y, d.y_ld, d.y_choff = y.data_ptr(), y_ld, y_choff
+    d.scale, d.shift, d.mean, d.invstd = scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+    d.slope, d.mode = slope, mode
+    d.g, d.g_ld, d.g_choff = g.data_ptr(), g_ld, g_choff
+    d.g2 = g2.data_ptr() if g2 is not None else None
+    d.g2_ld, d.g2_choff = g2_ld, g2_choff
+    d.dy, d.dy_ld, d.dy_choff = dy.data_ptr(), dy_ld, dy_choff
+    d.dgamma = dgamma.data_ptr() if dgamma is not None else None
+    d.dbeta = dbeta.data_ptr() if dbeta is not None else None
+    d.grad_scale = grad_scale
+    need = int(L.lib().mcamd_bn_act_bwd_workspace_bytes(C.byref(d)))
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.uint8, device=y.device)
+    check(L.lib().mcamd_bn_act_bwd(C.byref(d), ptr(workspace), workspace.numel(), stream_ptr()), "mcamd_bn_act_bwd")
+
+
+def bn_act_bwd_workspace_bytes(C_):
+    d = ActBwdDesc()
+    d.C = C_
+    return int(L.lib().mcamd_bn_act_bwd_workspace_bytes(C.byref(d)))
+
+
+def nchw_to_padded(src, dst, dst_ld, dst_choff=0, mul=1.0):
+    """fp32 NCHW tensor -> channels [choff, choff+C) of a padded NHWC fp16 buffer."""
+    _need_cuda(src, dst)
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    B, C_, H, W = src.shape
+    check(L.lib().mcamd_nchw_f32_to_padded_nhwc_f16(ptr(src), B, C_, H, W, mul, ptr(dst), dst_ld, dst_choff,
+                                                    stream_ptr()), "mcamd_nchw_f32_to_padded_nhwc_f16")
+
+
+# ------------------------------------------------------------------ pruning
+def kth_magnitude(tensors, k):
+    """-> device fp32[2] = (s[k], s[min(k+1, n-1)]) of the ascending |w| over all tensors."""
+    _need_cuda(*tensors)
+    n = len(tensors)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    counts = (C.c_int64 * n)(*[t.numel() for t in tensors])
+    dev = tensors[0].device
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    ws = torch.empty(int(L.lib().mcamd_kth_magnitude_workspace_bytes()), dtype=torch.uint8, device=dev)
+    check(L.lib().mcamd_kth_magnitude(ptrs, counts, n, k, ptr(out), ptr(ws), ws.numel(), stream_ptr()),
+          "mcamd_kth_magnitude")
+    return out
+
+
+def magnitude_mask(w, thr_dev):
+    mask = torch.empty_like(w)
+    check(L.lib().mcamd_magnitude_mask(ptr(w), w.numel(), ptr(thr_dev), ptr(mask), stream_ptr()), "mcamd_magnitude_mask")
+    return mask
+
+
+def filter_scores(w):
+    O, I, kh, kw = w.shape
+    scores = torch.empty(O, dtype=torch.float32, device=w.device)
+    ws = torch.empty(int(L.lib().mcamd_filter_scores_workspace_bytes(O)), dtype=torch.uint8, device=w.device)
+    check(L.lib().mcamd_filter_scores(ptr(w), O, I, kh, kw, ptr(scores), ptr(ws), ws.numel(), stream_ptr()),
+          "mcamd_filter_scores")
+    return scores
+
+
+def filter_mask(keep_i32, shape):
+    O = shape[0]
+    per = 1
+    for s in shape[1:]:
+        per *= s
+    mask = torch.empty(shape, dtype=torch.float32, device=keep_i32.device)
+    check(L.lib().mcamd_filter_mask(ptr(keep_i32), O, per, ptr(mask), stream_ptr()), "mcamd_filter_mask")
+    return mask
+
+
+def count_zeros(tensors):
+    dev = tensors[0].device
+    out = torch.zeros(1, dtype=torch.int64, device=dev)
+    for t in tensors:
+        check(L.lib().mcamd_count_zeros(ptr(t), t.numel(), ptr(out), stream_ptr()), "mcamd_count_zeros")
+    return int(out.item())
+
+
+def masked_residual(ws, masks):
+    dev = ws[0].device
+    out = torch.zeros(1, dtype=torch.float32, device=dev)
+    for w, m in zip(ws, masks):
+        check(L.lib().mcamd_masked_residual(ptr(w), ptr(m), w.numel(), ptr(out), stream_ptr()), "mcamd_masked_residual")
+    return float(out.item())

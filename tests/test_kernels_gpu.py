@@ -1,0 +1,294 @@
+"""GPU parity of every C-ABI primitive against torch-CPU fp32 math on the same
+(fp16-rounded) operands.  Tolerances: conv outputs are stored in fp16 after fp32
+accumulation, so the bound is 1e-3 relative L2 (north_star's activation
+tolerance); integer/bit results (masks, scores, order statistics) are exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from modelcompression_amd import ops  # noqa: E402
+from modelcompression_amd import _lib as L  # noqa: E402
+from util import (rel_l2, to_padded, raw_to_nchw, padded_to_nchw, halo_is_zero, nchw_to_raw, q16)  # noqa: E402
+
+TOL = 1e-3
+
+CONV_CASES = [
+    # B, H, W, cin, cout, k
+    (2, 16, 16, 32, 64, 3),
+    (2, 8, 8, 64, 32, 1),
+    (1, 13, 13, 128, 256, 3),     # M = 169: ragged M tile
+    (2, 20, 20, 32, 32, 3),
+    (3, 13, 13, 192, 64, 3),      # cin not a multiple of 64, cout 64 tile
+    (1, 26, 26, 64, 128, 1),
+    (2, 13, 13, 256, 128, 3),
+    (1, 12, 12, 40, 48, 3),       # channels padded to 64 (cin) / 48 outputs
+]
+
+
+def _rand_case(B, H, W, cin, cout, k, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (k * k * cin)) ** 0.5
+    return x, w
+
+
+@pytest.mark.parametrize("C,ld,choff", [(3, 4, 0), (32, 32, 0), (125, 128, 0), (64, 128, 32), (5, 32, 8)])
+def test_layout_nchw_to_padded(dev, C, ld, choff):
+    x = torch.randn(2, C, 10, 7)
+    buf = ops.alloc_padded(2, 10, 7, ld, dev)
+    ops.nchw_to_padded(x.to(dev), buf, ld, choff, mul=2.0)
+    got = padded_to_nchw(buf, 2, 10, 7, ld, C, choff)
+    assert torch.equal(got, (x * 2.0).half().float())
+    assert halo_is_zero(buf, 2, 10, 7, ld)
+    v = ops.padded_view(buf, 2, 10, 7, ld)
+    assert float(v[..., :choff].abs().sum()) == 0 and float(v[..., choff + C:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("bk", ["32", "64"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_raw_and_stats(dev, case, bk, monkeypatch):
+    monkeypatch.setenv("MCAMD_BK", bk)
+    B, H, W, cin, cout, k = case
+    x, w = _rand_case(*case)
+    xb, ld = to_padded(x.to(dev))
+    g = ops.geom(B, H, W, k, cin, cout, ld)
+    wp, _ = ops.pack_weights(g, w.to(dev).contiguous())
+    y_ld = ops.round_up(cout, 8)
+    y = torch.zeros(B * H * W * y_ld, dtype=torch.float16, device=dev)
+    rows = ops.stats_rows(g)
+    stats = torch.full((rows, 2, ops.round_up(cout, 128)), float("nan"), dtype=torch.float32, device=dev)
+    if cout % 8 == 0:
+        ops.conv_fwd_raw(g, xb, wp, y, y_ld, 0, stats)
+        got = raw_to_nchw(y, B, H, W, y_ld, cout)
+        ref = F.conv2d(q16(x), q16(w), None, 1, (k - 1) // 2)
+        assert rel_l2(got, ref) < TOL, "conv fwd raw"
+        s = stats.cpu().double().sum(0)
+        ref1 = got.double().sum((0, 2, 3))
+        ref2 = (got.double() ** 2).sum((0, 2, 3))
+        assert torch.allclose(s[0, :cout], ref1, rtol=1e-4, atol=1e-2)
+        assert torch.allclose(s[1, :cout], ref2, rtol=1e-4, atol=1e-2)
+    # fp32 NCHW epilogue with bias works for any cout
+    bias = torch.randn(cout)
+    out = torch.zeros(B, cout, H, W, device=dev)
+    ops.conv_fwd_nchw(g, xb, wp, out, bias.to(dev))
+    ref = F.conv2d(q16(x), q16(w), bias, 1, (k - 1) // 2)
+    assert rel_l2(out.cpu(), ref) < TOL, "conv fwd nchw"
+
+
+def test_conv_fwd_cout125_bias(dev):
+    B, H, W, cin, cout, k = 2, 13, 13, 256, 125, 1
+    x, w = _rand_case(B, H, W, cin, cout, k, seed=3)
+    bias = torch.randn(cout)
+    xb, ld = to_padded(x.to(dev))
+    g = ops.geom(B, H, W, k, cin, cout, ld)
+    wp, _ = ops.pack_weights(g, w.to(dev).contiguous())
+    out = torch.zeros(B, cout, H, W, device=dev)
+    ops.conv_fwd_nchw(g, xb, wp, out, bias.to(dev))
+    ref = F.conv2d(q16(x), q16(w), bias, 1, 0)
+    assert rel_l2(out.cpu(), ref) < TOL
+
+
+def test_conv_fwd_stem(dev):
+    B, H, W, cout = 2, 32, 48, 32
+    g0 = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 3, H, W, generator=g0)
+    w = torch.randn(cout, 3, 3, 3, generator=g0) * 0.3
+    xb, ld = to_padded(x.to(dev))
+    assert ld == 4
+    g = ops.geom(B, H, W, 3, 3, cout, 4, 0, stem=1)
+    wp, wd = ops.pack_weights(g, w.to(dev).contiguous())
+    assert wd is None
+    y = torch.zeros(B * H * W * cout, dtype=torch.float16, device=dev)
+    rows = ops.stats_rows(g)
+    stats = torch.zeros(rows, 2, 128, device=dev)
+    ops.conv_fwd_raw(g, xb, wp, y, cout, 0, stats)
+    got = raw_to_nchw(y, B, H, W, cout, cout)
+    ref = F.conv2d(q16(x), q16(w), None, 1, 1)
+    assert rel_l2(got, ref) < TOL
+
+
+def test_conv_fwd_padded_epilogue(dev):
+    B, H, W, cin, cout, k = 2, 14, 14, 64, 64, 3
+    x, w = _rand_case(B, H, W, cin, cout, k, seed=7)
+    scale, shift = torch.rand(cout) + 0.5, torch.randn(cout) * 0.2
+    xb, ld = to_padded(x.to(dev))
+    g = ops.geom(B, H, W, k, cin, cout, ld)
+    wp, _ = ops.pack_weights(g, w.to(dev).contiguous())
+    dst = ops.alloc_padded(B, H, W, 128, dev)
+    ops.conv_fwd_padded(g, xb, wp, dst, 128, 32, scale.to(dev), shift.to(dev), 0.1)
+    got = padded_to_nchw(dst, B, H, W, 128, cout, 32)
+    ref = F.leaky_relu(F.conv2d(q16(x), q16(w), None, 1, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), 0.1)
+    assert rel_l2(got, ref) < TOL
+    assert halo_is_zero(dst, B, H, W, 128)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_dgrad_wgrad(dev, case):
+    B, H, W, cin, cout, k = case
+    x, w = _rand_case(*case, seed=11)
+    gen = torch.Generator().manual_seed(12)
+    gy = torch.randn(B, cout, H, W, generator=gen)
+    mask = (torch.rand(cout, cin, k, k, generator=gen) > 0.4).float()
+    mask[0] = 0.0
+    xr = q16(x).requires_grad_(True)
+    wr = q16(w * mask).requires_grad_(True)
+    yr = F.conv2d(xr, wr * mask, None, 1, (k - 1) // 2)
+    yr.backward(q16(gy))
+    xb, ld = to_padded(x.to(dev))
+    g = ops.geom(B, H, W, k, cin, cout, ld)
+    _, wd = ops.pack_weights(g, w.to(dev).contiguous(), mask.to(dev).contiguous())
+    dyb, dy_ld = to_padded(gy.to(dev))
+    # dgrad, fp32 NCHW output
+    dx = torch.zeros(B, cin, H, W, device=dev)
+    ops.conv_dgrad_nchw(g, dyb, dy_ld, 0, wd, dx)
+    assert rel_l2(dx.cpu(), xr.grad) < TOL, "dgrad nchw"
+    if cin % 8 == 0:
+        out = torch.zeros(B * H * W * cin, dtype=torch.float16, device=dev)
+        ops.conv_dgrad_raw(g, dyb, dy_ld, 0, wd, out, cin)
+        assert rel_l2(raw_to_nchw(out, B, H, W, cin, cin), xr.grad) < TOL, "dgrad raw"
+    # wgrad with mask, grad scale and bias gradient
+    dw = torch.full((cout, cin, k, k), float("nan"), device=dev)
+    db = torch.zeros(cout, device=dev)
+    dyb2, _ = to_padded(gy.to(dev), mul=8.0)
+    ops.conv_wgrad(g, xb, dyb2, dy_ld, 0, dw, mask.to(dev).contiguous(), grad_scale=8.0, dbias=db)
+    assert rel_l2(dw.cpu(), wr.grad) < TOL, "wgrad"
+    assert bool((dw.cpu()[mask == 0] == 0).all()), "masked weight gradients must be exactly zero"
+    assert rel_l2(db.cpu(), q16(gy).sum((0, 2, 3))) < TOL
+
+
+def test_wgrad_stem(dev):
+    B, H, W, cout = 2, 24, 40, 32
+    gen = torch.Generator().manual_seed(13)
+    x = torch.rand(B, 3, H, W, generator=gen)
+    gy = torch.randn(B, cout, H, W, generator=gen)
+    w = torch.zeros(cout, 3, 3, 3, requires_grad=True)
+    F.conv2d(q16(x), w, None, 1, 1).backward(q16(gy))
+    xb, _ = to_padded(x.to(dev))
+    dyb, dy_ld = to_padded(gy.to(dev))
+    g = ops.geom(B, H, W, 3, 3, cout, 4, 0, stem=1)
+    dw = torch.zeros(cout, 3, 3, 3, device=dev)
+    ops.conv_wgrad(g, xb, dyb, dy_ld, 0, dw)
+    assert rel_l2(dw.cpu(), w.grad) < TOL
+
+
+def _bn_ref(y, gamma, beta, slope, mode, training_stats=True):
+    """fp32 reference of BN(train) -> leaky -> {plain, pool, reorg}; y is a leaf."""
+    z = F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5)
+    a = F.leaky_relu(z, slope)
+    if mode == L.DST_POOL:
+        return a, F.max_pool2d(a, 2, 2)
+    if mode == L.DST_REORG:
+        from oracle.darknet_ref import reorg
+        return a, reorg(a, 2)
+    return a, a
+
+
+@pytest.mark.parametrize("mode", [L.DST_PLAIN, L.DST_POOL, L.DST_REORG])
+@pytest.mark.parametrize("C", [32, 64, 256])
+def test_bn_act_fwd_bwd(dev, mode, C):
+    B, H, W = 3, 12, 10
+    gen = torch.Generator().manual_seed(20 + C)
+    y = q16(torch.randn(B, C, H, W, generator=gen) * 2 + 0.3)
+    gamma, beta = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen) * 0.1
+    dual = mode == L.DST_POOL
+    yl = y.clone().requires_grad_(True)
+    gl, bl = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    a, out = _bn_ref(yl, gl, bl, 0.1, mode)
+    gout = torch.randn(out.shape, generator=gen)
+    g2 = torch.randn(a.shape, generator=gen) if dual else None
+    loss = (out * q16(gout)).sum() + ((a * q16(g2)).sum() if dual else 0.0)
+    loss.backward()
+
+    # ---- device: statistics as the conv epilogue would deliver them (one slab row) ----
+    yb = nchw_to_raw(y, C)
+    stats = torch.zeros(1, 2, ops.round_up(C, 128), device=dev)
+    yd = y.to(dev).double()
+    stats[0, 0, :C] = yd.sum((0, 2, 3)).float()
+    stats[0, 1, :C] = (yd * yd).sum((0, 2, 3)).float()
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    scale, shift, mean, invstd = (torch.empty(C, device=dev) for _ in range(4))
+    ops.bn_coeffs(stats, C, B * H * W, gamma.to(dev), beta.to(dev), rm, rv, True, scale, shift, mean, invstd)
+    rm_ref, rv_ref = torch.zeros(C), torch.ones(C)
+    F.batch_norm(y, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    assert torch.allclose(rm.cpu(), rm_ref, rtol=1e-4, atol=1e-5) and torch.allclose(rv.cpu(), rv_ref, rtol=1e-4, atol=1e-5)
+
+    Ho, Wo = (H, W) if mode == L.DST_PLAIN else (H // 2, W // 2)
+    Cd = C * 4 if mode == L.DST_REORG else C
+    ld = Cd + 32
+    dst = ops.alloc_padded(B, Ho, Wo, ld, dev)
+    dst2 = ops.alloc_padded(B, H, W, C, dev) if dual else None
+    ops.bn_act_fwd(B, H, W, C, yb, C, 0, scale, shift, 0.1, mode, dst, ld, 32, dst2, C if dual else 0, 0)
+    assert rel_l2(padded_to_nchw(dst, B, Ho, Wo, ld, Cd, 32), out.detach()) < TOL
+    assert halo_is_zero(dst, B, Ho, Wo, ld)
+    if dual:
+        assert rel_l2(padded_to_nchw(dst2, B, H, W, C, C), a.detach()) < TOL
+
+    # ---- backward ----
+    S = 4.0
+    gb = nchw_to_raw(gout * S, ld, 32)
+    g2b = nchw_to_raw(g2 * S, C) if dual else None
+    dy = ops.alloc_padded(B, H, W, C, dev)
+    dgamma, dbeta = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    ops.bn_act_bwd(B, H, W, C, yb, C, 0, scale, shift, mean, invstd, 0.1, mode, gb, ld, 32, dy, C, 0, dgamma, dbeta,
+                   grad_scale=S, g2=g2b, g2_ld=C if dual else 0)
+    assert rel_l2(padded_to_nchw(dy, B, H, W, C, C) / S, yl.grad) < 2e-3
+    assert rel_l2(dgamma.cpu(), gl.grad) < TOL and rel_l2(dbeta.cpu(), bl.grad) < TOL
+    assert halo_is_zero(dy, B, H, W, C)
+
+
+def test_bn_coeffs_eval(dev):
+    C = 64
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C)
+    rm, rv = torch.randn(C), torch.rand(C) + 0.5
+    scale, shift = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    ops.bn_coeffs(None, C, 1, gamma.to(dev), beta.to(dev), rmd, rvd, False, scale, shift)
+    s_ref = gamma / torch.sqrt(rv + 1e-5)
+    assert torch.allclose(scale.cpu(), s_ref, rtol=1e-6) and torch.allclose(shift.cpu(), beta - rm * s_ref, rtol=1e-5, atol=1e-6)
+    assert torch.equal(rmd.cpu(), rm) and torch.equal(rvd.cpu(), rv)
+
+
+# ------------------------------------------------------------------ pruning primitives
+def test_kth_magnitude_and_mask(dev):
+    rng = np.random.default_rng(0)
+    parts = [rng.standard_normal(n).astype(np.float32) for n in (1000, 37, 250000, 1)]
+    parts[2][:500] = 0.0                                   # exact zeros and ties
+    parts[0][:10] = parts[0][10:20]
+    allw = np.sort(np.abs(np.concatenate(parts)))
+    ts = [torch.from_numpy(p).to(dev) for p in parts]
+    n = allw.size
+    for k in (0, 1, 499, 500, n // 3, n - 2, n - 1):
+        out = ops.kth_magnitude(ts, k).cpu().numpy()
+        assert out[0].view(np.uint32) == allw[k].view(np.uint32), k
+        assert out[1].view(np.uint32) == allw[min(k + 1, n - 1)].view(np.uint32), k
+    thr = torch.tensor([float(allw[n // 2])], device=dev)
+    m = ops.magnitude_mask(ts[2], thr).cpu().numpy()
+    assert np.array_equal(m, (np.abs(parts[2]) > allw[n // 2]).astype(np.float32))
+
+
+@pytest.mark.parametrize("shape", [(32, 3, 3, 3), (64, 32, 3, 3), (64, 128, 1, 1), (125, 1024, 1, 1), (256, 512, 1, 1),
+                                   (1024, 1280, 3, 3), (7, 5, 1, 1), (9, 9, 1, 1), (3, 130, 1, 1), (300, 17, 3, 3)])
+def test_filter_scores_bit_exact(dev, shape):
+    from oracle import prune_ref as P
+    rng = np.random.default_rng(sum(shape))
+    w = (rng.standard_normal(shape) * 0.1).astype(np.float32)
+    got = ops.filter_scores(torch.from_numpy(w).to(dev)).cpu().numpy()
+    ref = P.filter_scores(w)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_filter_mask_count_zeros_residual(dev):
+    keep = torch.tensor([1, 0, 1, 1, 0], dtype=torch.int32, device=dev)
+    m = ops.filter_mask(keep, (5, 4, 3, 3)).cpu()
+    ref = torch.ones(5, 4, 3, 3)
+    ref[1] = 0
+    ref[4] = 0
+    assert torch.equal(m, ref)
+    w = torch.randn(5, 4, 3, 3)
+    wz = (w * ref).to(dev)
+    assert ops.count_zeros([wz, torch.zeros(7, device=dev)]) == 2 * 36 + 7
+    assert ops.masked_residual([wz], [ref.to(dev)]) == 0.0
+    assert ops.masked_residual([w.to(dev)], [ref.to(dev)]) > 0.0
