@@ -185,6 +185,10 @@ int mcamd_magnitude_mask(const float* w, int64_t n, const float* threshold, floa
 size_t mcamd_filter_scores_workspace_bytes(int32_t cout);
 int mcamd_filter_scores(const float* w_oihw, int32_t cout, int32_t cin, int32_t kh, int32_t kw,
                         float* scores, void* workspace, size_t workspace_bytes, void* stream);
+/* Only the first stage: out[o] = sum(w[o]^2) / (cin*kh*kw) in numpy's summation order
+ * (prune_one_filter ranks before the /max step, methods.py:104-109).  Same workspace size. */
+int mcamd_filter_mean_square(const float* w_oihw, int32_t cout, int32_t cin, int32_t kh, int32_t kw,
+                             float* mean_sq, void* workspace, size_t workspace_bytes, void* stream);
 /* mask[o][...] = keep[o] ? 1.f : 0.f over a [cout][per_filter] tensor (methods.py:74). */
 int mcamd_filter_mask(const int32_t* keep, int32_t cout, int64_t per_filter, float* mask, void* stream);
 /* count of exact zeros in an fp32 tensor, added to *out (device int64) -- prune_rate, utils.py:76-80. */

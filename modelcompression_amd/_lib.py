@@ -73,6 +73,7 @@ SIGNATURES = {
     "mcamd_magnitude_mask": (C.c_int, [_P, _I64, _P, _P, _P]),
     "mcamd_filter_scores_workspace_bytes": (_SZ, [_I32]),
     "mcamd_filter_scores": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _SZ, _P]),
+    "mcamd_filter_mean_square": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _SZ, _P]),
     "mcamd_filter_mask": (C.c_int, [_P, _I32, _I64, _P, _P]),
     "mcamd_count_zeros": (C.c_int, [_P, _I64, _P, _P]),
     "mcamd_masked_residual": (C.c_int, [_P, _P, _I64, _P, _P]),

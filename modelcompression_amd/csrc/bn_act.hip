@@ -208,12 +208,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(ActBwdArgs a) {
             load8(a.g + gp * a.g_ld + a.g_choff + c8, gv);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                // argmax of the activation over the window, first maximum in (h, w) scan order
-                float best = zz[0][i] > 0.f ? zz[0][i] : zz[0][i] * a.slope;
+                // argmax over the window of the activation AS STORED (fp16) by the forward pass,
+                // first maximum in (h, w) scan order -- torch's max_pool2d tie rule on those values
+                float best = (float)(half_t)(zz[0][i] > 0.f ? zz[0][i] : zz[0][i] * a.slope);
                 int arg = 0;
 #pragma unroll
                 for (int k = 1; k < NP; ++k) {
-                    float av = zz[k][i] > 0.f ? zz[k][i] : zz[k][i] * a.slope;
+                    float av = (float)(half_t)(zz[k][i] > 0.f ? zz[k][i] : zz[k][i] * a.slope);
                     if (av > best) {
                         best = av;
                         arg = k;

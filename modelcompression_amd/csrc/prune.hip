@@ -235,25 +235,46 @@ __global__ void filter_normalize_kernel(const float* ms, int O, float* scores) {
 
 extern "C" size_t mcamd_filter_scores_workspace_bytes(int32_t cout) { return (size_t)cout * 10 * sizeof(float); }
 
-extern "C" int mcamd_filter_scores(const float* w_oihw, int32_t cout, int32_t cin, int32_t kh, int32_t kw, float* scores,
-                                   void* workspace, size_t workspace_bytes, void* stream) {
-    MCAMD_REQUIRE(w_oihw && scores && workspace && cout > 0 && cin > 0 && kh > 0 && kw > 0, "filter_scores: bad argument");
-    MCAMD_REQUIRE(kh * kw <= 9, "filter_scores: kernel larger than 3x3 unsupported");
-    MCAMD_REQUIRE(cin <= (128 << PW_MAXDEPTH) && cout <= (128 << PW_MAXDEPTH), "filter_scores: tensor too large");
+static int filter_args_ok(const float* w, int32_t cout, int32_t cin, int32_t kh, int32_t kw, const void* out,
+                          const void* workspace, size_t workspace_bytes, const char* what) {
+    MCAMD_REQUIRE(w && out && workspace && cout > 0 && cin > 0 && kh > 0 && kw > 0, "%s: bad argument", what);
+    MCAMD_REQUIRE(kh * kw <= 9, "%s: kernel larger than 3x3 unsupported", what);
+    MCAMD_REQUIRE(cin <= (128 << PW_MAXDEPTH) && cout <= (128 << PW_MAXDEPTH), "%s: tensor too large", what);
     if (workspace_bytes < mcamd_filter_scores_workspace_bytes(cout)) {
-        mcamd_set_error("filter_scores: workspace too small");
+        mcamd_set_error("%s: workspace too small", what);
         return MCAMD_EWORKSPACE;
     }
-    hipStream_t st = (hipStream_t)stream;
-    float* partial = (float*)workspace;
-    float* ms = partial + (size_t)cout * 9;
+    return MCAMD_OK;
+}
+
+static void launch_mean_square(const float* w, int cout, int cin, int kh, int kw, float* partial, float* ms,
+                               hipStream_t st) {
     int KK = kh * kw;
     if (KK > 1) {
         int total = cout * KK;
-        hipLaunchKernelGGL(filter_partial_kernel, dim3((total + 63) / 64), dim3(64), 0, st, w_oihw, cout, cin, KK, partial);
+        hipLaunchKernelGGL(filter_partial_kernel, dim3((total + 63) / 64), dim3(64), 0, st, w, cout, cin, KK, partial);
     }
-    hipLaunchKernelGGL(filter_meansq_kernel, dim3((cout + 63) / 64), dim3(64), 0, st, w_oihw, (const float*)partial, cout,
-                       cin, kh, kw, ms);
+    hipLaunchKernelGGL(filter_meansq_kernel, dim3((cout + 63) / 64), dim3(64), 0, st, w, (const float*)partial, cout, cin,
+                       kh, kw, ms);
+}
+
+extern "C" int mcamd_filter_mean_square(const float* w_oihw, int32_t cout, int32_t cin, int32_t kh, int32_t kw,
+                                        float* mean_sq, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = filter_args_ok(w_oihw, cout, cin, kh, kw, mean_sq, workspace, workspace_bytes, "filter_mean_square");
+    if (rc) return rc;
+    launch_mean_square(w_oihw, cout, cin, kh, kw, (float*)workspace, mean_sq, (hipStream_t)stream);
+    MCAMD_LAUNCH_CHECK("filter_mean_square");
+    return MCAMD_OK;
+}
+
+extern "C" int mcamd_filter_scores(const float* w_oihw, int32_t cout, int32_t cin, int32_t kh, int32_t kw, float* scores,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = filter_args_ok(w_oihw, cout, cin, kh, kw, scores, workspace, workspace_bytes, "filter_scores");
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    float* ms = partial + (size_t)cout * 9;
+    launch_mean_square(w_oihw, cout, cin, kh, kw, partial, ms, st);
     hipLaunchKernelGGL(filter_normalize_kernel, dim3(1), dim3(256), 0, st, (const float*)ms, cout, scores);
     MCAMD_LAUNCH_CHECK("filter_scores");
     return MCAMD_OK;

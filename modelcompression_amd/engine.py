@@ -1,0 +1,330 @@
+"""Fused MI355X execution plan for a Darknet/YOLOv2 block list.
+
+`Darknet.forward` (reference src/nets.py:720-774) walks the cfg blocks and calls one torch
+module per block.  Here the same block list is compiled once per batch size into a static
+launch plan over libmcamd.so:
+
+  forward, per [convolutional] block
+      mcamd_conv_fwd      implicit-GEMM MFMA conv -> raw fp16 output + BN partial sums
+      mcamd_bn_coeffs     batch (train) or running (eval) statistics -> scale/shift
+      mcamd_bn_act_fwd    BN + LeakyReLU, fused with the following [maxpool] / [reorg],
+                          written straight into the consumer's padded NHWC buffer
+                          ([route] concat = channel slices of one buffer, no copy)
+      the last, linear block writes fp32 NCHW logits (+bias) from the conv epilogue
+  backward, reverse order
+      mcamd_bn_act_bwd    pool/reorg/route + LeakyReLU + BN backward -> dY (padded NHWC)
+      mcamd_conv_wgrad    dW * mask (fp32 OIHW, straight into the flat gradient buffer)
+      mcamd_conv_dgrad    gradient wrt the block input
+
+Activations live in HBM as padded NHWC fp16 for the whole step; weights are re-packed
+(fp32 master * mask -> fp16) once per optimizer step.  All buffers are allocated once per
+batch size; a B=64 training step holds ~7 GB of the 288 GB.
+"""
+import torch
+
+from . import ops
+from . import _lib as L
+from ._lib import McamdError
+
+
+class _T:
+    """Where a block output lives: channel slice [choff, choff+C) of a padded NHWC buffer."""
+    __slots__ = ("buf", "ld", "choff", "C", "H", "W")
+
+    def __init__(self, buf, ld, choff, C, H, W):
+        self.buf, self.ld, self.choff, self.C, self.H, self.W = buf, ld, choff, C, H, W
+
+
+class _Layer:
+    pass
+
+
+def _resolve_routes(blocks):
+    """Per models-index: (type, [source tensor ids]); tensor id -1 is the network input."""
+    ops_ = []
+    for ind, b in enumerate(blocks[1:]):
+        t = b["type"]
+        if t in ("convolutional", "maxpool", "reorg"):
+            ops_.append((t, [ind - 1]))
+        elif t == "route":
+            ls = [int(i) if int(i) > 0 else int(i) + ind for i in b["layers"].split(",")]
+            ops_.append((t, ls))
+        elif t in ("region", "cost"):
+            ops_.append((t, []))
+        else:
+            raise NotImplementedError("block type %r is outside the YOLOv2 conv hot path" % t)
+    return ops_
+
+
+class Engine:
+    def __init__(self, model, B, H, W, device, grad_scale=256.0):
+        self.model, self.B, self.device = model, B, device
+        self.grad_scale = float(grad_scale)
+        self.serial = 0
+        self._packed_sig = None
+        self._build_plan(H, W)
+
+    # ------------------------------------------------------------------ plan
+    def _build_plan(self, H0, W0):
+        model, B, dev = self.model, self.B, self.device
+        blocks = model.blocks
+        bops = _resolve_routes(blocks)
+        n = len(bops)
+
+        def alias(t):                      # single-layer routes are aliases
+            while t >= 0 and bops[t][0] == "route" and len(bops[t][1]) == 1:
+                t = bops[t][1][0]
+            return t
+
+        srcs = [[alias(s) for s in o[1]] for o in bops]
+        consumers = {}
+        for ind, (t, _) in enumerate(bops):
+            if t == "route" and len(srcs[ind]) == 1:
+                continue
+            for s in srcs[ind]:
+                consumers.setdefault(s, []).append(ind)
+
+        # shapes of every tensor id
+        shape = {-1: (int(blocks[0]["channels"]), H0, W0)}
+        for ind, (t, _) in enumerate(bops):
+            if t == "convolutional":
+                c, h, w = shape[srcs[ind][0]]
+                assert int(blocks[ind + 1]["stride"]) == 1, "only stride-1 convolutions (YOLOv2)"
+                shape[ind] = (int(blocks[ind + 1]["filters"]), h, w)
+            elif t == "maxpool":
+                c, h, w = shape[srcs[ind][0]]
+                if int(blocks[ind + 1]["size"]) != 2 or int(blocks[ind + 1]["stride"]) != 2:
+                    raise NotImplementedError("only maxpool size=2 stride=2 is on the YOLOv2 path")
+                shape[ind] = (c, h // 2, w // 2)
+            elif t == "reorg":
+                c, h, w = shape[srcs[ind][0]]
+                assert int(blocks[ind + 1]["stride"]) == 2
+                shape[ind] = (4 * c, h // 2, w // 2)
+            elif t == "route":
+                if len(srcs[ind]) == 1:
+                    shape[ind] = shape[srcs[ind][0]]
+                else:
+                    (c1, h, w), (c2, h2, w2) = shape[srcs[ind][0]], shape[srcs[ind][1]]
+                    assert (h, w) == (h2, w2)
+                    shape[ind] = (c1 + c2, h, w)
+
+        # fusion: what each conv's activation kernel produces
+        conv_inds = [i for i, (t, _) in enumerate(bops) if t == "convolutional"]
+        fused = {}
+        for ci in conv_inds:
+            cons = consumers.get(ci, [])
+            pools = [c for c in cons if bops[c][0] == "maxpool"]
+            reorgs = [c for c in cons if bops[c][0] == "reorg"]
+            if len(pools) == 1 and len(cons) == 1:
+                fused[ci] = (L.DST_POOL, pools[0], None)
+            elif len(pools) == 1 and not reorgs:
+                fused[ci] = (L.DST_POOL, pools[0], ci)          # pooled + full-resolution copy (route source)
+            elif len(reorgs) == 1 and len(cons) == 1:
+                fused[ci] = (L.DST_REORG, reorgs[0], None)
+            elif not pools and not reorgs:
+                fused[ci] = (L.DST_PLAIN, ci, None)
+            else:
+                raise NotImplementedError("unsupported consumer pattern after conv block %d" % ci)
+        for ind, (t, _) in enumerate(bops):
+            if t in ("maxpool", "reorg") and not any(f[1] == ind for f in fused.values()):
+                raise NotImplementedError("stand-alone %s block %d (not directly after a conv)" % (t, ind))
+
+        # placement: concat members share one buffer
+        place = {}
+        self.bufs = []
+
+        def new_buf(Bn, h, w, ld):
+            self.bufs.append(ops.alloc_padded(Bn, h, w, ld, dev))
+            return len(self.bufs) - 1
+
+        for ind, (t, _) in enumerate(bops):
+            if t == "route" and len(srcs[ind]) == 2:
+                a, b = srcs[ind]
+                (ca, h, w), (cb, _, _) = shape[a], shape[b]
+                assert ca % 8 == 0 and a not in place and b not in place
+                ld = ops.round_up(ca + cb, 32)
+                bid = new_buf(B, h, w, ld)
+                place[a] = _T(bid, ld, 0, ca, h, w)
+                place[b] = _T(bid, ld, ca, cb, h, w)
+                place[ind] = _T(bid, ld, 0, ca + cb, h, w)
+        cin0 = shape[-1][0]
+        first_k = int(blocks[conv_inds[0] + 1]["size"])
+        self.stem = (cin0 == 3 and first_k == 3)
+        ld0 = 4 if self.stem else ops.round_up(cin0, 32)
+        place[-1] = _T(new_buf(B, H0, W0, ld0), ld0, 0, cin0, H0, W0)
+        materialized = set()
+        for ci in conv_inds:
+            mode, out_id, out2_id = fused[ci]
+            for tid in (out_id, out2_id):
+                if tid is None:
+                    continue
+                materialized.add(tid)
+                if tid not in place and consumers.get(tid):
+                    c, h, w = shape[tid]
+                    ld = ops.round_up(c, 32)
+                    place[tid] = _T(new_buf(B, h, w, ld), ld, 0, c, h, w)
+
+        # layers
+        self.layers = []
+        by_src = {}
+        bn_names = []
+        for li, ci in enumerate(conv_inds):
+            blk = blocks[ci + 1]
+            seq = model.models[ci]
+            lay = _Layer()
+            lay.index, lay.li = ci, li
+            lay.conv = seq[0]
+            lay.bn = seq[1] if int(blk["batch_normalize"]) else None
+            lay.slope = 0.1 if blk["activation"] == "leaky" else 1.0
+            if blk["activation"] not in ("leaky", "linear"):
+                raise NotImplementedError("activation %r" % blk["activation"])
+            src = srcs[ci][0]
+            lay.src = src
+            tin = place[src]
+            lay.tin = tin
+            lay.cin, lay.H, lay.W = shape[src]
+            lay.cout = shape[ci][0]
+            lay.k = int(blk["size"])
+            pad = int((lay.k - 1) / 2) if int(blk["pad"]) else 0
+            if pad != (lay.k - 1) // 2 or lay.k not in (1, 3):
+                raise NotImplementedError("conv block %d: only 'same' 1x1/3x3 convolutions" % ci)
+            lay.stem = 1 if (li == 0 and self.stem) else 0
+            lay.geom = ops.geom(B, lay.H, lay.W, lay.k, lay.cin, lay.cout, tin.ld, tin.choff, lay.stem)
+            lay.M = B * lay.H * lay.W
+            lay.mode, lay.out_id, lay.out2_id = fused[ci]
+            lay.is_last = lay.bn is None
+            if lay.is_last:
+                if lay.slope != 1.0 or consumers.get(ci):
+                    raise NotImplementedError("a conv block without batch_normalize must be the final linear block")
+            else:
+                if lay.cout % 8 or 256 % (lay.cout // 8):
+                    raise NotImplementedError("BN channel count %d (needs 8 * power of two)" % lay.cout)
+            by_src.setdefault(src, []).append(lay)
+            self.layers.append(lay)
+        for s, ls in by_src.items():
+            if len(ls) > 1:
+                raise NotImplementedError("tensor %d feeds %d conv blocks; one consumer conv per tensor is supported" % (s, len(ls)))
+        # a concat tensor's members are consumed through the concat's consumer
+        self.consumer_of = {}
+        for lay in self.layers:
+            self.consumer_of[lay.src] = lay
+            if lay.src >= 0 and bops[lay.src][0] == "route" and len(srcs[lay.src]) == 2:
+                for m in srcs[lay.src]:
+                    self.consumer_of[m] = lay
+
+        f32 = dict(dtype=torch.float32, device=dev)
+        wbytes = 0
+        for lay in self.layers:
+            g = lay.geom
+            nf, nd = ops.packed_elems(g)
+            lay.wp = torch.empty(nf, dtype=ops.HALF, device=dev)
+            lay.wd = torch.empty(nd, dtype=ops.HALF, device=dev) if (nd and lay.li > 0) else None
+            wbytes = max(wbytes, ops.wgrad_workspace_bytes(g))
+            lay.cout_p = ops.round_up(lay.cout, 32)
+            lay.dy = ops.alloc_padded(B, lay.H, lay.W, lay.cout_p, dev)
+            lay.gin = None
+            if lay.li > 0:
+                lay.gin = torch.empty(lay.M * lay.tin.ld, dtype=ops.HALF, device=dev)
+            if not lay.is_last:
+                lay.y = torch.empty(lay.M * lay.cout, dtype=ops.HALF, device=dev)
+                lay.stats = torch.empty(ops.stats_rows(g), 2, ops.round_up(lay.cout, 128), **f32)
+                lay.scale, lay.shift, lay.mean, lay.invstd = (torch.empty(lay.cout, **f32) for _ in range(4))
+                lay.out_t = place.get(lay.out_id)
+                lay.out2_t = place.get(lay.out2_id) if lay.out2_id is not None else None
+                if lay.out_t is None:
+                    raise NotImplementedError("conv block %d output is never consumed" % lay.index)
+        self.wgrad_ws = torch.empty(max(wbytes, 16), dtype=torch.uint8, device=dev)
+        maxc = max(l.cout for l in self.layers)
+        self.bwd_ws = torch.empty(ops.bn_act_bwd_workspace_bytes(maxc), dtype=torch.uint8, device=dev)
+        self.params = list(model.parameters())
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += p.numel()
+        self.total_params = off
+        self.out_shape = (B, self.layers[-1].cout, self.layers[-1].H, self.layers[-1].W)
+
+    # ------------------------------------------------------------------ weights
+    def _signature(self):
+        sig = []
+        for lay in self.layers:
+            w = lay.conv.weight
+            m = lay.conv.mask if lay.conv.mask_flag else None
+            sig.append((w.data_ptr(), w._version, None if m is None else (m.data_ptr(), m._version)))
+        return tuple(sig)
+
+    def pack(self, force=False):
+        """fp32 master * mask -> fp16 kernel layouts (replaces layers.py:59's per-forward multiply)."""
+        sig = self._signature()
+        if not force and sig == self._packed_sig and not self.model._weights_dirty:
+            return
+        for lay in self.layers:
+            w = lay.conv.weight.data
+            if w.dtype != torch.float32 or not w.is_contiguous():
+                raise McamdError("conv weights must be contiguous fp32 (master copy)")
+            mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
+            ops.pack_weights(lay.geom, w, mask, True, lay.wd is not None, lay.wp, lay.wd)
+        self._packed_sig = sig
+        self.model._weights_dirty = False
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, training):
+        B = self.B
+        if tuple(x.shape) != (B, self.layers[0].cin, self.layers[0].H, self.layers[0].W):
+            raise McamdError("engine built for input %s, got %s" % ((B, self.layers[0].cin, self.layers[0].H, self.layers[0].W), tuple(x.shape)))
+        self.pack(force=training)
+        self.serial += 1
+        tin = self.layers[0].tin
+        ops.nchw_to_padded(x.detach().contiguous().float(), self.bufs[tin.buf], tin.ld, tin.choff)
+        out = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
+        for lay in self.layers:
+            xin = self.bufs[lay.tin.buf]
+            if lay.is_last:
+                bias = lay.conv.bias.data if lay.conv.bias is not None else None
+                ops.conv_fwd_nchw(lay.geom, xin, lay.wp, out, bias)
+                continue
+            bn = lay.bn
+            ops.conv_fwd_raw(lay.geom, xin, lay.wp, lay.y, lay.cout, 0, lay.stats if training else None)
+            ops.bn_coeffs(lay.stats if training else None, lay.cout, lay.M, bn.weight.data, bn.bias.data,
+                          bn.running_mean, bn.running_var, training, lay.scale, lay.shift, lay.mean, lay.invstd,
+                          momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps)
+            t, t2 = lay.out_t, lay.out2_t
+            ops.bn_act_fwd(B, lay.H, lay.W, lay.cout, lay.y, lay.cout, 0, lay.scale, lay.shift, lay.slope, lay.mode,
+                           self.bufs[t.buf], t.ld, t.choff,
+                           self.bufs[t2.buf] if t2 is not None else None,
+                           t2.ld if t2 is not None else 0, t2.choff if t2 is not None else 0)
+        if training:
+            bns = [lay.bn.num_batches_tracked for lay in self.layers if lay.bn is not None]
+            if bns:
+                torch._foreach_add_(bns, 1)
+        return out
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, grad_out):
+        """grad wrt the returned logits -> one flat fp32 gradient buffer; returns per-parameter views."""
+        S = self.grad_scale
+        flat = torch.zeros(self.total_params, dtype=torch.float32, device=self.device)
+        views = [flat[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.params)]
+        gmap = {id(p): v for p, v in zip(self.params, views)}
+        for lay in reversed(self.layers):
+            if lay.is_last:
+                ops.nchw_to_padded(grad_out.detach().contiguous().float(), lay.dy, lay.cout_p, 0, S)
+            else:
+                cons = self.consumer_of[lay.out_id]
+                t = lay.out_t
+                g2 = g2_ld = g2_choff = None
+                if lay.out2_id is not None and lay.out2_id in self.consumer_of:
+                    c2, t2 = self.consumer_of[lay.out2_id], lay.out2_t
+                    g2, g2_ld, g2_choff = c2.gin, c2.tin.ld, t2.choff
+                ops.bn_act_bwd(self.B, lay.H, lay.W, lay.cout, lay.y, lay.cout, 0, lay.scale, lay.shift, lay.mean,
+                               lay.invstd, lay.slope, lay.mode, cons.gin, cons.tin.ld, t.choff, lay.dy, lay.cout_p, 0,
+                               gmap[id(lay.bn.weight)], gmap[id(lay.bn.bias)], S, g2, g2_ld or 0, g2_choff or 0,
+                               self.bwd_ws)
+            mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
+            dbias = gmap[id(lay.conv.bias)] if lay.conv.bias is not None else None
+            ops.conv_wgrad(lay.geom, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0, gmap[id(lay.conv.weight)], mask, S,
+                           dbias, self.wgrad_ws)
+            if lay.li > 0:
+                # gradient wrt this block's input slice, written into gin at the slice's channel offset
+                ops.conv_dgrad_raw(lay.geom, lay.dy, lay.cout_p, 0, lay.wd, lay.gin, lay.tin.ld, lay.tin.choff)
+        return flat, views

@@ -1,0 +1,497 @@
+"""Model API of the reference's src/nets.py for the YOLOv2 path, MI355X-native underneath.
+
+Kept surface (reference file:line): parse_cfg nets.py:39-73, print_cfg 75-190, the weight
+(de)serialisers 194-279, MaxPoolStride1/Reorg/GlobalAvgPool2d/EmptyModule 640-688,
+Darknet 692-1061 (blocks, models, loss, width/height, anchors..., header, seen, forward,
+print_network, create_network, load_weights, save_weights, set_masks), getYOLOv2 1069-1074.
+`state_dict()` keys and `parameters()` order are identical to the reference's, so its
+checkpoints and mask lists interchange.
+
+What differs: `Darknet.forward` does not call one torch module per block.  The block list is
+compiled into a fused HIP launch plan (engine.py) that runs on the GPU only; a CPU tensor
+raises instead of falling back to a PyTorch path.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ._lib import McamdError
+from .pruning.weightPruning.layers import MaskedConv2d
+from .pruning.weightPruning.methods import quick_filter_prune, weight_prune  # noqa: F401 (reference re-exports)
+from .pruning.weightPruning.utils import prune_rate, are_masks_consistent  # noqa: F401
+from .region_loss import RegionLoss, build_targets  # noqa: F401
+
+USE_GPU = torch.cuda.is_available()
+
+
+# ----------------------------------------------------------------------------- cfg
+def parse_cfg(cfgfile, verbose=0):
+    """Darknet .cfg -> list of dict blocks (nets.py:39-73).  A line is only rstrip()ped before
+    the blank/'#' test; '[name]' opens a block; [convolutional] gets the int default
+    batch_normalize=0; every other line must split on '=' into exactly two parts; the key
+    'type' is stored as '_type'; values are stripped strings."""
+    blocks = []
+    block = None
+    with open(cfgfile, 'r') as fp:
+        for raw in fp:
+            line = raw.rstrip()
+            if line == '' or line[0] == '#':
+                continue
+            if line[0] == '[':
+                if block:
+                    if verbose:
+                        print('')
+                        print(' - block : ', block)
+                    blocks.append(block)
+                block = dict()
+                block['type'] = line.lstrip('[').rstrip(']')
+                if block['type'] == 'convolutional':
+                    block['batch_normalize'] = 0
+            else:
+                key, value = line.split('=')
+                key = key.strip()
+                if key == 'type':
+                    key = '_type'
+                block[key] = value.strip()
+    if block:
+        blocks.append(block)
+    return blocks
+
+
+def print_cfg(blocks):
+    """Layer table like nets.py:75-190 (index, type, filters, size, input -> output)."""
+    print('layer     filters    size              input                output')
+    prev_w = prev_h = prev_f = 0
+    out_f, out_w, out_h = [], [], []
+    ind = -2
+    for block in blocks:
+        ind += 1
+        t = block['type']
+        if t == 'net':
+            prev_w, prev_h, prev_f = int(block['width']), int(block['height']), int(block['channels'])
+            continue
+        if t == 'convolutional':
+            f, k, s = int(block['filters']), int(block['size']), int(block['stride'])
+            pad = (k - 1) // 2 if int(block['pad']) else 0
+            w, h = (prev_w + 2 * pad - k) // s + 1, (prev_h + 2 * pad - k) // s + 1
+            print('%5d %-6s %4d  %d x %d / %d   %3d x %3d x%4d   ->   %3d x %3d x%4d' % (
+                ind, 'conv', f, k, k, s, prev_w, prev_h, prev_f, w, h, f))
+            prev_w, prev_h, prev_f = w, h, f
+        elif t == 'maxpool':
+            k, s = int(block['size']), int(block['stride'])
+            w, h = prev_w // s, prev_h // s
+            print('%5d %-6s       %d x %d / %d   %3d x %3d x%4d   ->   %3d x %3d x%4d' % (
+                ind, 'max', k, k, s, prev_w, prev_h, prev_f, w, h, prev_f))
+            prev_w, prev_h = w, h
+        elif t == 'reorg':
+            s = int(block['stride'])
+            f, w, h = s * s * prev_f, prev_w // s, prev_h // s
+            print('%5d %-6s              / %d   %3d x %3d x%4d   ->   %3d x %3d x%4d' % (
+                ind, 'reorg', s, prev_w, prev_h, prev_f, w, h, f))
+            prev_w, prev_h, prev_f = w, h, f
+        elif t == 'route':
+            layers = [int(i) if int(i) > 0 else int(i) + ind for i in block['layers'].split(',')]
+            print('%5d %-6s %s' % (ind, 'route', ' '.join(str(l) for l in layers)))
+            prev_w, prev_h = out_w[layers[0]], out_h[layers[0]]
+            prev_f = sum(out_f[l] for l in layers)
+        elif t == 'region':
+            print('%5d %-6s' % (ind, 'detection'))
+        else:
+            print('unknown type %s' % t)
+        out_f.append(prev_f), out_w.append(prev_w), out_h.append(prev_h)
+
+
+# ----------------------------------------------------------------------------- weight files
+def convert2cpu(gpu_matrix):
+    return torch.FloatTensor(gpu_matrix.size()).copy_(gpu_matrix)
+
+
+def load_param(file, param):
+    """nets.py:256-259: the next param.numel() float32 values of the open file."""
+    buf = np.fromfile(file, dtype=np.float32, count=param.numel())
+    if buf.size != param.numel():
+        raise EOFError("weights file ended inside a %s parameter" % (tuple(param.shape),))
+    param.data.copy_(torch.from_numpy(buf.reshape(tuple(param.shape))))
+
+
+def load_conv(file, conv_model):
+    load_param(file, conv_model.bias)
+    load_param(file, conv_model.weight)
+
+
+def load_conv_bn(file, conv_model, bn_model):
+    """nets.py:270-276 order: bn.bias, bn.weight, running_mean, running_var, conv.weight."""
+    load_param(file, bn_model.bias)
+    load_param(file, bn_model.weight)
+    load_param(file, bn_model.running_mean)
+    load_param(file, bn_model.running_var)
+    load_param(file, conv_model.weight)
+
+
+def load_fc(file, fc_model):
+    load_param(file, fc_model.bias)
+    load_param(file, fc_model.weight)
+
+
+def _tofile(t, fp):
+    t.detach().cpu().numpy().astype(np.float32, copy=False).tofile(fp)
+
+
+def save_conv(fp, conv_model):
+    _tofile(conv_model.bias.data, fp)
+    _tofile(conv_model.weight.data, fp)
+
+
+def save_conv_bn(fp, conv_model, bn_model):
+    _tofile(bn_model.bias.data, fp)
+    _tofile(bn_model.weight.data, fp)
+    _tofile(bn_model.running_mean, fp)
+    _tofile(bn_model.running_var, fp)
+    _tofile(conv_model.weight.data, fp)
+
+
+def save_fc(fp, fc_model):
+    _tofile(fc_model.bias.data, fp)
+    _tofile(fc_model.weight.data, fp)
+
+
+# ----------------------------------------------------------------------------- glue modules
+class MaxPoolStride1(nn.Module):
+    def forward(self, x):
+        return F.max_pool2d(F.pad(x, (0, 1, 0, 1), mode='replicate'), 2, stride=1)
+
+
+class Reorg(nn.Module):
+    """nets.py:648-667 (marvis ordering): out channel = (hs*stride + ws)*C + c.  Inside a
+    Darknet the reorg is fused into the producing conv's activation kernel; this module keeps
+    the class for API parity and for use on its own."""
+
+    def __init__(self, stride=2):
+        super(Reorg, self).__init__()
+        self.stride = stride
+
+    def forward(self, x):
+        s = self.stride
+        assert x.dim() == 4
+        B, C, H, W = x.shape
+        assert H % s == 0 and W % s == 0
+        x = x.view(B, C, H // s, s, W // s, s).transpose(3, 4).contiguous()
+        x = x.view(B, C, (H // s) * (W // s), s * s).transpose(2, 3).contiguous()
+        x = x.view(B, C, s * s, H // s, W // s).transpose(1, 2).contiguous()
+        return x.view(B, s * s * C, H // s, W // s)
+
+
+class GlobalAvgPool2d(nn.Module):
+    def forward(self, x):
+        N, C, H, W = x.shape
+        return F.avg_pool2d(x, (H, W)).view(N, C)
+
+
+class EmptyModule(nn.Module):
+    def forward(self, x):
+        return x
+
+
+# ----------------------------------------------------------------------------- autograd bridge
+class _DarknetFn(torch.autograd.Function):
+    """logits = engine.forward(x); backward hands every parameter its gradient as a view of one
+    flat fp32 buffer (bucket-free all-reduce for data parallel training)."""
+
+    @staticmethod
+    def forward(ctx, model, engine, training, x, *params):
+        out = engine.forward(x, training)
+        ctx.model, ctx.engine, ctx.serial, ctx.training = model, engine, engine.serial, training
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        eng = ctx.engine
+        if ctx.needs_input_grad[3]:
+            raise McamdError("gradient wrt the input image is not provided (the first conv has no dgrad)")
+        if not ctx.training:
+            raise McamdError("backward through an eval-mode forward is not supported; call model.train()")
+        if eng.serial != ctx.serial:
+            raise McamdError("backward() must follow the forward() it belongs to (activations are kept in place)")
+        flat, views = eng.backward(gout)
+        ctx.model._last_flat_grad = flat
+        hook = ctx.model._grad_hook
+        if hook is not None:
+            hook(flat)
+        return (None, None, None, None) + tuple(views)
+
+
+# ----------------------------------------------------------------------------- Darknet
+class Darknet(nn.Module):
+    def __init__(self, cfgfile, verbose=0):
+        super(Darknet, self).__init__()
+        self.blocks = parse_cfg(cfgfile)
+        self.models = self.create_network(self.blocks)  # merge conv, bn, leaky
+        self.loss = self.models[len(self.models) - 1]
+
+        self.width = int(self.blocks[0]['width'])
+        self.height = int(self.blocks[0]['height'])
+
+        if self.blocks[(len(self.blocks) - 1)]['type'] == 'region':
+            self.anchors = self.loss.anchors
+            self.num_anchors = self.loss.num_anchors
+            self.anchor_step = self.loss.anchor_step
+            self.num_classes = self.loss.num_classes
+            if verbose:
+                print('  -- [Darknet] anchors %s num_anchors %s anchor_step %s num_classes %s' % (
+                    self.anchors, self.num_anchors, self.anchor_step, self.num_classes))
+
+        self.header = torch.IntTensor([0, 0, 0, 0])
+        self.seen = 0
+        # engine state (not part of the reference surface)
+        self._engines = {}
+        self._weights_dirty = True
+        self._grad_hook = None          # callable(flat_grad) run at the end of backward (data parallel)
+        self._last_flat_grad = None
+        self.grad_scale = 256.0         # fp16 gradient scaling inside the engine, undone in fp32
+
+    # ---- engine plumbing
+    def _apply(self, fn, *args, **kwargs):
+        self._engines = {}
+        self._weights_dirty = True
+        return super(Darknet, self)._apply(fn, *args, **kwargs)
+
+    def invalidate_packed(self):
+        """Call after modifying weights through `.data` outside optimizer.step / set_masks / load_weights."""
+        self._weights_dirty = True
+
+    def load_state_dict(self, *args, **kwargs):
+        self._weights_dirty = True
+        return super(Darknet, self).load_state_dict(*args, **kwargs)
+
+    def _engine_for(self, x):
+        from .engine import Engine
+        key = (tuple(x.shape), x.device.index, float(self.grad_scale))
+        eng = self._engines.get(key)
+        if eng is None:
+            if len(self._engines) >= 2:
+                self._engines.pop(next(iter(self._engines)))
+            eng = Engine(self, x.shape[0], x.shape[2], x.shape[3], x.device, self.grad_scale)
+            self._engines[key] = eng
+        return eng
+
+    def forward(self, x):
+        """nets.py:720-774: returns the last conv block's output (the [region] block is skipped;
+        the caller applies the loss).  NCHW fp32 in, NCHW fp32 out."""
+        if not x.is_cuda:
+            raise McamdError("Darknet.forward needs a CUDA (MI355X) tensor: modelcompression_amd has no CPU path "
+                             "(the CPU restatement lives in oracle/ and is test infrastructure)")
+        eng = self._engine_for(x)
+        params = tuple(self.parameters())
+        return _DarknetFn.apply(self, eng, self.training, x, *params)
+
+    def print_network(self):
+        print_cfg(self.blocks)
+
+    def create_network(self, blocks):
+        """nets.py:779-895: one module per non-[net] block; conv block =
+        Sequential(conv{id}: MaskedConv2d, bn{id}: BatchNorm2d, leaky{id}: LeakyReLU(0.1))."""
+        models = nn.ModuleList()
+        prev_filters = 3
+        out_filters = []
+        conv_id = 0
+        for block in blocks:
+            t = block['type']
+            if t == 'net':
+                prev_filters = int(block['channels'])
+                continue
+            elif t == 'convolutional':
+                conv_id = conv_id + 1
+                batch_normalize = int(block['batch_normalize'])
+                filters = int(block['filters'])
+                kernel_size = int(block['size'])
+                stride = int(block['stride'])
+                is_pad = int(block['pad'])
+                pad = int((kernel_size - 1) / 2) if is_pad else 0
+                activation = block['activation']
+                model = nn.Sequential()
+                if batch_normalize:
+                    model.add_module('conv{0}'.format(conv_id),
+                                     MaskedConv2d(prev_filters, filters, kernel_size, stride, pad, bias=False))
+                    model.add_module('bn{0}'.format(conv_id), nn.BatchNorm2d(filters))
+                else:
+                    model.add_module('conv{0}'.format(conv_id),
+                                     MaskedConv2d(prev_filters, filters, kernel_size, stride, pad))
+                if activation == 'leaky':
+                    model.add_module('leaky{0}'.format(conv_id), nn.LeakyReLU(0.1, inplace=True))
+                elif activation == 'relu':
+                    model.add_module('relu{0}'.format(conv_id), nn.ReLU(inplace=True))
+                prev_filters = filters
+                out_filters.append(prev_filters)
+                models.append(model)
+            elif t == 'maxpool':
+                pool_size = int(block['size'])
+                stride = int(block['stride'])
+                model = nn.MaxPool2d(pool_size, stride) if stride > 1 else MaxPoolStride1()
+                out_filters.append(prev_filters)
+                models.append(model)
+            elif t == 'avgpool':
+                out_filters.append(prev_filters)
+                models.append(GlobalAvgPool2d())
+            elif t == 'softmax':
+                out_filters.append(prev_filters)
+                models.append(nn.Softmax())
+            elif t == 'cost':
+                if block['_type'] == 'sse':
+                    model = nn.MSELoss(reduction='mean')
+                elif block['_type'] == 'L1':
+                    model = nn.L1Loss(reduction='mean')
+                elif block['_type'] == 'smooth':
+                    model = nn.SmoothL1Loss(reduction='mean')
+                out_filters.append(1)
+                models.append(model)
+            elif t == 'reorg':
+                stride = int(block['stride'])
+                prev_filters = stride * stride * prev_filters
+                out_filters.append(prev_filters)
+                models.append(Reorg(stride))
+            elif t == 'route':
+                layers = block['layers'].split(',')
+                ind = len(models)
+                layers = [int(i) if int(i) > 0 else int(i) + ind for i in layers]
+                if len(layers) == 1:
+                    prev_filters = out_filters[layers[0]]
+                elif len(layers) == 2:
+                    assert (layers[0] == ind - 1)
+                    prev_filters = out_filters[layers[0]] + out_filters[layers[1]]
+                out_filters.append(prev_filters)
+                models.append(EmptyModule())
+            elif t == 'shortcut':
+                ind = len(models)
+                prev_filters = out_filters[ind - 1]
+                out_filters.append(prev_filters)
+                models.append(EmptyModule())
+            elif t == 'connected':
+                filters = int(block['output'])
+                if block['activation'] == 'linear':
+                    model = nn.Linear(prev_filters, filters)
+                elif block['activation'] == 'leaky':
+                    model = nn.Sequential(nn.Linear(prev_filters, filters), nn.LeakyReLU(0.1, inplace=True))
+                elif block['activation'] == 'relu':
+                    model = nn.Sequential(nn.Linear(prev_filters, filters), nn.ReLU(inplace=True))
+                prev_filters = filters
+                out_filters.append(prev_filters)
+                models.append(model)
+            elif t == 'region':
+                loss = RegionLoss()
+                anchors = block['anchors'].split(',')
+                loss.anchors = [float(i) for i in anchors]
+                loss.num_classes = int(block['classes'])
+                loss.num_anchors = int(block['num'])
+                loss.anchor_step = len(loss.anchors) / loss.num_anchors
+                loss.object_scale = float(block['object_scale'])
+                loss.noobject_scale = float(block['noobject_scale'])
+                loss.class_scale = float(block['class_scale'])
+                loss.coord_scale = float(block['coord_scale'])
+                out_filters.append(prev_filters)
+                models.append(loss)
+            else:
+                print('unknown type %s' % (block['type']))
+        return models
+
+    def load_weights(self, weightfile):
+        """nets.py:897-948: 3 x int32 major/minor/revision, `seen` as int64 when
+        major*10+minor >= 2 (both < 1000) else int32, then the conv blocks in order."""
+        with open(weightfile, mode='rb') as f:
+            major = int(np.fromfile(f, dtype=np.int32, count=1)[0])
+            minor = int(np.fromfile(f, dtype=np.int32, count=1)[0])
+            revision = int(np.fromfile(f, dtype=np.int32, count=1)[0])
+            if major * 10 + minor >= 2 and major < 1000 and minor < 1000:
+                seen = int(np.fromfile(f, dtype=np.int64, count=1)[0])
+            else:
+                seen = int(np.fromfile(f, dtype=np.int32, count=1)[0])
+            # like the reference, the header values are read and dropped here (nets.py:899-905):
+            # only load_weights_old() keeps `header` / `seen`.
+            del revision, seen
+            ind = -2
+            for block in self.blocks:
+                if ind >= len(self.models):
+                    break
+                ind = ind + 1
+                if block['type'] == 'net':
+                    continue
+                elif block['type'] == 'convolutional':
+                    model = self.models[ind]
+                    if int(block['batch_normalize']):
+                        load_conv_bn(f, model[0], model[1])
+                    else:
+                        load_conv(f, model[0])
+                elif block['type'] == 'connected':
+                    model = self.models[ind]
+                    load_fc(f, model[0] if block['activation'] != 'linear' else model)
+        self._weights_dirty = True
+
+    def load_weights_old(self, weightfile):
+        """nets.py:950-1005: 4 x int32 header (kept in self.header, seen = header[3]), then floats."""
+        with open(weightfile, 'rb') as f:
+            header = np.fromfile(f, count=4, dtype=np.int32)
+            self.header = torch.from_numpy(header)
+            self.seen = self.header[3]
+            ind = -2
+            for block in self.blocks:
+                ind = ind + 1
+                if block['type'] == 'convolutional':
+                    model = self.models[ind]
+                    if int(block['batch_normalize']):
+                        load_conv_bn(f, model[0], model[1])
+                    else:
+                        load_conv(f, model[0])
+                elif block['type'] == 'connected':
+                    model = self.models[ind]
+                    load_fc(f, model[0] if block['activation'] != 'linear' else model)
+        self._weights_dirty = True
+
+    def save_weights(self, outfile, cutoff=0):
+        """nets.py:1007-1051: header int32 [major, minor, revision, seen] (so a saved file always
+        re-loads through the int32-`seen` branch when the header is the default [0,0,0,*])."""
+        if cutoff <= 0:
+            cutoff = len(self.blocks) - 1
+        with open(outfile, 'wb') as fp:
+            self.header[3] = int(self.seen)
+            self.header.numpy().tofile(fp)
+            ind = -1
+            for blockId in range(1, cutoff + 1):
+                ind = ind + 1
+                block = self.blocks[blockId]
+                if block['type'] == 'convolutional':
+                    model = self.models[ind]
+                    if int(block['batch_normalize']):
+                        save_conv_bn(fp, model[0], model[1])
+                    else:
+                        save_conv(fp, model[0])
+                elif block['type'] == 'connected':
+                    model = self.models[ind]
+                    save_fc(fp, model[0] if block['activation'] != 'linear' else model)
+
+    def set_masks(self, masks):
+        """nets.py:1053-1061: hand masks[count] to every MaskedConv2d in module order.  Like the
+        reference, failures are swallowed (a too-short list leaves the remaining layers unmasked)."""
+        count = 0
+        for m in self.modules():
+            try:
+                if m[0].name == 'MaskedConv2d':
+                    m[0].set_mask(masks[count])
+                    count += 1
+            except Exception:
+                pass
+        self._weights_dirty = True
+
+
+def debug_weights(model):
+    for name, param in model.named_parameters():
+        if param.requires_grad and param.grad is not None:
+            print('  -- [DEBUG] : ', name, '\t  - \t', round(param.grad.data.sum().item(), 3), '   [', param.shape, ']')
+
+
+def getYOLOv2(cfgfile, weightfile):
+    """nets.py:1069-1074."""
+    model = Darknet(cfgfile)
+    model.load_weights(weightfile)
+    if USE_GPU:
+        model.cuda()
+    return model

@@ -202,6 +202,15 @@ def filter_scores(w):
     return scores
 
 
+def filter_mean_square(w):
+    O, I, kh, kw = w.shape
+    ms = torch.empty(O, dtype=torch.float32, device=w.device)
+    ws = torch.empty(int(L.lib().mcamd_filter_scores_workspace_bytes(O)), dtype=torch.uint8, device=w.device)
+    check(L.lib().mcamd_filter_mean_square(ptr(w), O, I, kh, kw, ptr(ms), ptr(ws), ws.numel(), stream_ptr()),
+          "mcamd_filter_mean_square")
+    return ms
+
+
 def filter_mask(keep_i32, shape):
     O = shape[0]
     per = 1

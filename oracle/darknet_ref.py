@@ -147,13 +147,46 @@ def reorg(x, stride=2):
     return x.view(B, hs * ws * C, H // hs, W // ws)
 
 
-def forward(blocks, state, x, training=False, masks=None, record=None, conv_out=None):
+class _StoreFp16(torch.autograd.Function):
+    """A tensor that the HIP engine keeps in HBM as fp16: rounded on the way forward, and its
+    gradient (also stored as fp16 by the engine) rounded on the way back."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.half().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.half().float()
+
+
+class _GradFp16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t):
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.half().float()
+
+
+def forward(blocks, state, x, training=False, masks=None, record=None, conv_out=None, storage=None):
     """Returns the last conv block's output (the region block is skipped,
     nets.py:761-762).  `masks`: list indexed by conv order, applied as
     `weight * mask` (layers.py:59).  `record`: dict filled with every block
     output by models index.  `conv_out`: dict filled with raw conv outputs
-    (before BN) by conv id, kept in the autograd graph."""
+    (before BN) by conv id, kept in the autograd graph.
+
+    `storage="fp16"`: same fp32 arithmetic, but every tensor the HIP engine stores in
+    HBM as fp16 (input image, masked weights, raw conv outputs, block outputs and the
+    gradients flowing back through them) is rounded to fp16 at that point.  Comparing the
+    engine with THIS run isolates kernel errors from the (ill-conditioned) response of a
+    BatchNorm/LeakyReLU network to fp16 rounding; comparing this run with the plain fp32
+    run measures that response."""
+    q = (lambda t: _StoreFp16.apply(t)) if storage == "fp16" else (lambda t: t)
     outputs, ci = {}, 0
+    if storage == "fp16":
+        x = x.half().float()
     for ind, op in enumerate(plan(blocks)):
         t = op["type"]
         if t == "conv":
@@ -162,8 +195,12 @@ def forward(blocks, state, x, training=False, masks=None, record=None, conv_out=
             if masks is not None:
                 w = w * masks[ci]
             ci += 1
+            if storage == "fp16":
+                w = w + (w.half().float() - w).detach()      # fp16 operand, fp32 master gradient
             bias = None if op["bn"] else state[p + "conv%d.bias" % i]
             x = F.conv2d(x, w, bias, op["stride"], op["pad"], 1, 1)
+            if storage == "fp16":
+                x = q(x) if op["bn"] else _GradFp16.apply(x)  # logits leave in fp32; their gradient arrives as fp16
             if conv_out is not None:
                 conv_out[i] = x
             if op["bn"]:
@@ -174,13 +211,16 @@ def forward(blocks, state, x, training=False, masks=None, record=None, conv_out=
                 x = F.leaky_relu(x, 0.1)
             elif op["act"] == "relu":
                 x = F.relu(x)
+            if op["bn"]:
+                x = q(x)
         elif t == "maxpool":
             if op["stride"] > 1:
                 x = F.max_pool2d(x, op["size"], op["stride"])
             else:
                 x = F.max_pool2d(F.pad(x, (0, 1, 0, 1), mode="replicate"), 2, stride=1)
+            x = q(x)
         elif t == "reorg":
-            x = reorg(x, op["stride"])
+            x = q(reorg(x, op["stride"]))
         elif t == "route":
             ls = op["layers"]
             x = outputs[ls[0]] if len(ls) == 1 else torch.cat((outputs[ls[0]], outputs[ls[1]]), 1)
