@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Headline benchmark: YOLOv2-VOC dense fwd+bwd(+SGD step) images/sec at 416x416 on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One step = model(x) -> sum-of-logits loss -> backward (HIP engine) -> [gradient all-reduce]
+-> torch.optim.SGD step (lr 1e-5, momentum .9, weight_decay .0005*B: reference train.py:144-147)
+on one resident synthetic batch of B=64 images per GPU (BASELINE.json configs[1]).
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, the 128x128 implicit-GEMM
+MFMA convolution (forward + dgrad launches), timed live with HIP events on the launch stream;
+`cpu_baseline` is the oracle (PyTorch-CPU restatement of the reference) on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP16_TFLOPS = 2500.0       # MI355X dense fp16 MFMA peak (MI355X_MICROARCH.md)
+FWD_BWD_GFLOP_PER_IMG = 87.782
+
+
+def cpu_baseline(batch, steps):
+    """Oracle fwd+bwd on the host cores: bounded sample of the same workload (B=`batch`)."""
+    from oracle import darknet_ref as O
+    from modelcompression_amd import YOLOV2_VOC_CFG
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(ncpu, int(os.environ.get("MCAMD_CPU_THREADS", "16")))))   # the GPU box's CPU share
+    blocks = O.parse_cfg(YOLOV2_VOC_CFG)
+    state = O.init_state(blocks, seed=0)
+    keys = O.param_keys(blocks)
+    for k in keys:
+        state[k].requires_grad_(True)
+    x = torch.rand(batch, 3, 416, 416, generator=torch.Generator().manual_seed(0))
+    opt = torch.optim.SGD([state[k] for k in keys], lr=1e-5, momentum=0.9, weight_decay=0.0005 * batch)
+    times = []
+    for it in range(steps + 1):
+        t0 = time.time()
+        out = O.forward(blocks, state, x, training=True)
+        opt.zero_grad()
+        out.sum().backward()
+        opt.step()
+        if it > 0:
+            times.append(time.time() - t0)
+    dt = sum(times) / len(times)
+    return {"value": round(batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "B=%d fwd+bwd+SGD x%d steps of the same YOLOv2-VOC 416x416 workload (oracle, fp32 oneDNN)" % (batch, steps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--layer-table", default="", help="write the per-launch timing table to this file")
+    args = ap.parse_args()
+
+    from modelcompression_amd import nets, dp, YOLOV2_VOC_CFG, ops
+    from modelcompression_amd.synthetic import init_synthetic, synthetic_batch
+
+    rank, world = dp.init_from_env()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    model = nets.Darknet(YOLOV2_VOC_CFG)
+    init_synthetic(model, seed=0)
+    model.to(dev).train()
+    B = args.batch
+    opt = torch.optim.SGD(model.parameters(), lr=1e-5, momentum=0.9, dampening=0, weight_decay=0.0005 * B)
+    reducer = dp.attach(model) if world > 1 else None
+    x = synthetic_batch(B, 416, 416, seed=rank, device=dev)   # resident in HBM before the timed region
+
+    def step():
+        out = model(x)
+        loss = out.float().sum()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    eng = list(model._engines.values())[0]
+    eng.events = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    events, eng.events = eng.events, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the dominant kernel: igemm_kernel<128,128,64,64,BK> (fwd + dgrad launches)
+    per = {}
+    for tag, lay, e0, e1 in events:
+        ms = e0.elapsed_time(e1)
+        key = (tag, lay.li)
+        a = per.setdefault(key, [0.0, 0, lay])
+        a[0] += ms
+        a[1] += 1
+    dom_ms = dom_flop = 0.0
+    dom_n = 0
+    tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
+    rows = []
+    for (tag, li), (ms, n, lay) in sorted(per.items(), key=lambda kv: (kv[0][1], kv[0][0])):
+        fl = eng.conv_flops(lay)
+        avg = ms / n
+        tile = ops.tile_info(lay.geom, dgrad=(tag == "dgrad")) if tag != "wgrad" else None
+        tot[tag][0] += avg
+        tot[tag][1] += fl
+        rows.append("%-6s conv%-2d %4dx%-4d cin %4d cout %4d k%d  %8.3f ms  %8.1f TFLOP/s  tile %s" % (
+            tag, li + 1, lay.H, lay.W, lay.cin, lay.cout, lay.k, avg, fl / avg / 1e9, tile))
+        if tile is not None and tile[0] == 128 and tile[1] == 128:
+            dom_ms += ms
+            dom_flop += fl * n
+            dom_n += n
+    achieved = dom_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    step_ms = dt / args.steps * 1e3
+    if rank == 0 and args.layer_table:
+        with open(args.layer_table, "w") as f:
+            f.write("\n".join(rows) + "\n")
+            for tag, (ms, fl) in tot.items():
+                f.write("TOTAL %-6s %8.3f ms/step  %8.1f TFLOP/s\n" % (tag, ms, fl / ms / 1e9 if ms else 0))
+            f.write("step %.3f ms; conv kernels %.3f ms\n" % (step_ms, sum(v[0] for v in tot.values())))
+
+    if rank != 0:
+        return
+    value = world * B * args.steps / dt
+    res = {
+        "metric": "images/sec (fwd+bwd, 416x416)", "value": round(value, 2), "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
+        "config": {"workload": "YOLOv2-VOC dense (0%% prune) fwd+bwd+SGD step, B=%d per GPU, 416x416 (BASELINE configs[1])" % B,
+                   "global_batch": world * B, "input": "3x416x416", "parallelism": "dp%d" % world,
+                   "conv_tflops_whole_step": round(value * FWD_BWD_GFLOP_PER_IMG / 1e3, 1),
+                   "frac_of_fp16_mfma_peak_whole_step": round(value * FWD_BWD_GFLOP_PER_IMG / 1e3 / (PEAK_FP16_TFLOPS * world), 4)},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": None,
+                     "kernel": "igemm_kernel<128,128,64,64,*> (conv fwd + dgrad launches)",
+                     "launches_per_step": dom_n // max(args.steps, 1),
+                     "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(args.cpu_batch, 2)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

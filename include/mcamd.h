@@ -86,6 +86,10 @@ typedef struct mcamd_conv_epilogue {
 /* Rows of the BatchNorm partial-sum slab a forward launch of this geometry writes. */
 int32_t mcamd_conv_stats_rows(const mcamd_conv_geom* g);
 
+/* Workgroup tile {BM, BN, BK} the forward (dgrad == 0) or dgrad launch of this geometry uses
+ * (which igemm_kernel<BM,BN,..,BK> instance shows up in a profile). */
+int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int32_t out[3]);
+
 /* Packed-weight sizes (elements of fp16) for a geometry. */
 int64_t mcamd_packed_elems_fwd(const mcamd_conv_geom* g);
 int64_t mcamd_packed_elems_dgrad(const mcamd_conv_geom* g);

@@ -56,6 +56,7 @@ SIGNATURES = {
     "mcamd_arch": (C.c_char_p, []),
     "mcamd_last_error": (C.c_char_p, []),
     "mcamd_conv_stats_rows": (_I32, [C.POINTER(ConvGeom)]),
+    "mcamd_conv_tile_info": (C.c_int, [C.POINTER(ConvGeom), _I32, C.POINTER(_I32)]),
     "mcamd_packed_elems_fwd": (_I64, [C.POINTER(ConvGeom)]),
     "mcamd_packed_elems_dgrad": (_I64, [C.POINTER(ConvGeom)]),
     "mcamd_pack_weights": (C.c_int, [C.POINTER(ConvGeom), _P, _P, _P, _P, _P]),

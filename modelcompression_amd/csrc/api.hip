@@ -189,6 +189,13 @@ extern "C" int32_t mcamd_conv_stats_rows(const mcamd_conv_geom* g) {
     return mcamd_igemm_rows((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g));
 }
 
+extern "C" int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int32_t out[3]) {
+    if (check_geom(g, "conv_tile_info")) return MCAMD_EINVAL;
+    MCAMD_REQUIRE(out, "conv_tile_info: null output");
+    mcamd_igemm_tile(dgrad ? g->cin : g->cout, dgrad ? cout_p_of(g) : cin_tap_of(g), out);
+    return MCAMD_OK;
+}
+
 extern "C" int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const void* wp_fwd, const mcamd_conv_epilogue* epi,
                               void* stream) {
     if (check_geom(g, "conv_fwd")) return MCAMD_EINVAL;

@@ -10,17 +10,33 @@
 // ------------------------------------------------------------------------------------
 // batch statistics -> affine coefficients
 // ------------------------------------------------------------------------------------
-__global__ void bn_coeffs_kernel(const float* stats, int rows, int ld, int C, double count, const float* gamma,
-                                 const float* beta, float* rmean, float* rvar, float momentum, float eps, int training,
-                                 float* scale, float* shift, float* save_mean, float* save_invstd) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double mean, var;
-    if (training) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int p = 0; p < rows; ++p) {
+// One block per 32 channels, 32 row groups x 32 channels: the slab rows are reduced in parallel
+// (coalesced 128-byte reads), then across the row groups through LDS, in double.
+__global__ __launch_bounds__(1024) void bn_coeffs_kernel(const float* stats, int rows, int ld, int C, double count,
+                                                         const float* gamma, const float* beta, float* rmean,
+                                                         float* rvar, float momentum, float eps, int training,
+                                                         float* scale, float* shift, float* save_mean,
+                                                         float* save_invstd) {
+    __shared__ double red[2][32][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    double s1 = 0.0, s2 = 0.0;
+    if (training && c < C) {
+        for (int p = ry; p < rows; p += 32) {
             s1 += (double)stats[((long long)p * 2 + 0) * ld + c];
             s2 += (double)stats[((long long)p * 2 + 1) * ld + c];
+        }
+    }
+    red[0][ry][cx] = s1;
+    red[1][ry][cx] = s2;
+    __syncthreads();
+    if (ry != 0 || c >= C) return;
+    double mean, var;
+    if (training) {
+        s1 = s2 = 0.0;
+        for (int k = 0; k < 32; ++k) {
+            s1 += red[0][k][cx];
+            s2 += red[1][k][cx];
         }
         mean = s1 / count;
         var = s2 / count - mean * mean;  // biased variance (normalisation)
@@ -273,14 +289,27 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(ActBwdArgs a) {
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* slab, int nblocks, int C, double count, float inv_scale,
-                                       float* dgamma, float* dbeta, float* coef) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* slab, int nblocks, int C, double count,
+                                                               float inv_scale, float* dgamma, float* dbeta,
+                                                               float* coef) {
+    __shared__ double red[2][32][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
     double sb = 0.0, sg = 0.0;
-    for (int p = 0; p < nblocks; ++p) {
-        sb += (double)slab[((long long)p * 2 + 0) * C + c];
-        sg += (double)slab[((long long)p * 2 + 1) * C + c];
+    if (c < C) {
+        for (int p = ry; p < nblocks; p += 32) {
+            sb += (double)slab[((long long)p * 2 + 0) * C + c];
+            sg += (double)slab[((long long)p * 2 + 1) * C + c];
+        }
+    }
+    red[0][ry][cx] = sb;
+    red[1][ry][cx] = sg;
+    __syncthreads();
+    if (ry != 0 || c >= C) return;
+    sb = sg = 0.0;
+    for (int k = 0; k < 32; ++k) {
+        sb += red[0][k][cx];
+        sg += red[1][k][cx];
     }
     if (dbeta) dbeta[c] = (float)(sb * inv_scale);
     if (dgamma) dgamma[c] = (float)(sg * inv_scale);
@@ -338,7 +367,7 @@ extern "C" int mcamd_bn_coeffs(const float* stats, int32_t stats_rows, int32_t s
                                float* save_mean, float* save_invstd, void* stream) {
     MCAMD_REQUIRE(C > 0 && gamma && beta && running_mean && running_var && scale && shift, "bn_coeffs: null argument");
     MCAMD_REQUIRE(!training || (stats && stats_rows > 0 && stats_ld >= C && count > 0), "bn_coeffs: bad statistics slab");
-    hipLaunchKernelGGL(bn_coeffs_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, stats_rows,
+    hipLaunchKernelGGL(bn_coeffs_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, stats, stats_rows,
                        stats_ld, C, (double)count, gamma, beta, running_mean, running_var, momentum, eps, training,
                        scale, shift, save_mean, save_invstd);
     MCAMD_LAUNCH_CHECK("bn_coeffs");
@@ -435,7 +464,7 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
         MCAMD_REQUIRE(false, "bn_act_bwd: bad mode %d", d->mode);
     BWD_LAUNCH(0)
     MCAMD_LAUNCH_CHECK("bn_act_bwd reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + 63) / 64), dim3(64), 0, st, (const float*)a.slab, grid, d->C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + 31) / 32), dim3(1024), 0, st, (const float*)a.slab, grid, d->C,
                        count, 1.0f / d->grad_scale, d->dgamma, d->dbeta, coef);
     MCAMD_LAUNCH_CHECK("bn_act_bwd finalize");
     BWD_LAUNCH(1)

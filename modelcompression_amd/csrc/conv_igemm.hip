@@ -272,6 +272,11 @@ static TileCfg pick_tile(int n, int cin_tap) {
     return t;
 }
 
+void mcamd_igemm_tile(int n, int cin_tap, int out[3]) {
+    TileCfg t = pick_tile(n, cin_tap);
+    out[0] = t.bm, out[1] = t.bn, out[2] = t.bk;
+}
+
 int mcamd_igemm_mtiles(long long M) { return (int)((M + 127) / 128); }
 
 // Number of persistent workgroups along M (== rows of the BN-statistics slab).

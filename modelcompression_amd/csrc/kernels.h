@@ -48,6 +48,7 @@ struct WgradPlan {
     size_t bytes;
 };
 
+void mcamd_igemm_tile(int n, int cin_tap, int out[3]);
 int mcamd_igemm_mtiles(long long M);
 int mcamd_igemm_rows(long long M, int n, int cin_tap);
 int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st);

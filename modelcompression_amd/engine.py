@@ -62,6 +62,7 @@ class Engine:
         self.grad_scale = float(grad_scale)
         self.serial = 0
         self._packed_sig = None
+        self.events = None            # list of (tag, layer, start, end) HIP events while profiling
         self._build_plan(H, W)
 
     # ------------------------------------------------------------------ plan
@@ -244,6 +245,22 @@ class Engine:
         self.total_params = off
         self.out_shape = (B, self.layers[-1].cout, self.layers[-1].H, self.layers[-1].W)
 
+    # ------------------------------------------------------------------ per-kernel timing
+    def _timed(self, tag, lay, fn, *args, **kw):
+        """Run one library call; when profiling, bracket it with HIP events on the launch stream."""
+        if self.events is None:
+            return fn(*args, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*args, **kw)
+        e1.record()
+        self.events.append((tag, lay, e0, e1))
+        return r
+
+    def conv_flops(self, lay):
+        """Algorithmic FLOPs of one forward conv launch (2 * M * Cout * Cin * k*k, unpadded)."""
+        return 2.0 * lay.M * lay.cout * lay.cin * lay.k * lay.k
+
     # ------------------------------------------------------------------ weights
     def _signature(self):
         sig = []
@@ -281,10 +298,10 @@ class Engine:
             xin = self.bufs[lay.tin.buf]
             if lay.is_last:
                 bias = lay.conv.bias.data if lay.conv.bias is not None else None
-                ops.conv_fwd_nchw(lay.geom, xin, lay.wp, out, bias)
+                self._timed('fwd', lay, ops.conv_fwd_nchw, lay.geom, xin, lay.wp, out, bias)
                 continue
             bn = lay.bn
-            ops.conv_fwd_raw(lay.geom, xin, lay.wp, lay.y, lay.cout, 0, lay.stats if training else None)
+            self._timed('fwd', lay, ops.conv_fwd_raw, lay.geom, xin, lay.wp, lay.y, lay.cout, 0, lay.stats if training else None)
             ops.bn_coeffs(lay.stats if training else None, lay.cout, lay.M, bn.weight.data, bn.bias.data,
                           bn.running_mean, bn.running_var, training, lay.scale, lay.shift, lay.mean, lay.invstd,
                           momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps)
@@ -322,9 +339,10 @@ class Engine:
                                self.bwd_ws)
             mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
             dbias = gmap[id(lay.conv.bias)] if lay.conv.bias is not None else None
-            ops.conv_wgrad(lay.geom, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0, gmap[id(lay.conv.weight)], mask, S,
-                           dbias, self.wgrad_ws)
+            self._timed('wgrad', lay, ops.conv_wgrad, lay.geom, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
+                        gmap[id(lay.conv.weight)], mask, S, dbias, self.wgrad_ws)
             if lay.li > 0:
                 # gradient wrt this block's input slice, written into gin at the slice's channel offset
-                ops.conv_dgrad_raw(lay.geom, lay.dy, lay.cout_p, 0, lay.wd, lay.gin, lay.tin.ld, lay.tin.choff)
+                self._timed('dgrad', lay, ops.conv_dgrad_raw, lay.geom, lay.dy, lay.cout_p, 0, lay.wd, lay.gin, lay.tin.ld,
+                            lay.tin.choff)
         return flat, views

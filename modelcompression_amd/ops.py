@@ -57,6 +57,12 @@ def pack_weights(g, w, mask=None, want_fwd=True, want_dgrad=True, out_fwd=None, 
     return out_fwd, out_dgrad
 
 
+def tile_info(g, dgrad=False):
+    out = (C.c_int32 * 3)()
+    check(L.lib().mcamd_conv_tile_info(C.byref(g), 1 if dgrad else 0, out), "mcamd_conv_tile_info")
+    return tuple(out)
+
+
 def stats_rows(g):
     return int(L.lib().mcamd_conv_stats_rows(C.byref(g)))
 
