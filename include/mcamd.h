@@ -161,6 +161,9 @@ typedef struct mcamd_act_bwd_desc {
     void* dy; int32_t dy_ld, dy_choff;      /* out: padded NHWC fp16 gradient wrt raw conv output */
     float* dgamma; float* dbeta;            /* out fp32 [C], already divided by grad_scale (may be NULL) */
     float grad_scale;          /* the incoming gradients are grad_scale x the true ones (fp16 range) */
+    const float* dy_keep;      /* optional fp32 [C]: 0 marks a fully pruned filter; its dY channel is written as
+                                  zero (its weights are zero, so dgrad/wgrad never need it -- and a dead filter has
+                                  zero batch variance, which would otherwise blow dY up by 1/sqrt(eps)) */
 } mcamd_act_bwd_desc;
 size_t mcamd_bn_act_bwd_workspace_bytes(const mcamd_act_bwd_desc* d);
 int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, size_t workspace_bytes, void* stream);

@@ -43,7 +43,8 @@ class ActBwdDesc(C.Structure):
                 ("g", C.c_void_p), ("g_ld", C.c_int32), ("g_choff", C.c_int32),
                 ("g2", C.c_void_p), ("g2_ld", C.c_int32), ("g2_choff", C.c_int32),
                 ("dy", C.c_void_p), ("dy_ld", C.c_int32), ("dy_choff", C.c_int32),
-                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("grad_scale", C.c_float)]
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("grad_scale", C.c_float),
+                ("dy_keep", C.c_void_p)]
 
 
 EPI_RAW_F16, EPI_NCHW_F32, EPI_PAD_F16 = 0, 1, 2

@@ -76,10 +76,13 @@ __device__ __forceinline__ void load8(const half_t* p, float* v) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
 }
+__device__ __forceinline__ half_t sat_half(float v) {  // saturate instead of overflowing to inf (inf * 0 = NaN downstream)
+    return (half_t)fminf(fmaxf(v, -65504.f), 65504.f);
+}
 __device__ __forceinline__ void store8(half_t* p, const float* v) {
     h8_t h;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) h[i] = (half_t)v[i];
+    for (int i = 0; i < 8; ++i) h[i] = sat_half(v[i]);
     *(h8_t*)p = h;
 }
 __device__ __forceinline__ void loadf8(const float* p, float* v) {
@@ -161,6 +164,7 @@ struct ActBwdArgs {
     half_t* dy;
     float* slab;         // [nblocks][2][C]
     const float* coef;   // [2][C]: c1 = sum(gz)/count, c2 = sum(gz*xhat)/count
+    const float* dy_keep;  // optional [C]: 0 for fully pruned filters (their dY is not needed and is zeroed)
     int B, H, W, C;
     int y_ld, y_choff, g_ld, g_choff, g2_ld, g2_choff, dy_ld, dy_choff;
     float slope;
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(ActBwdArgs a) {
     constexpr int NP = MODE == MCAMD_DST_PLAIN ? 1 : 4;
     const int CH = a.C >> 3;
     const int c8 = (threadIdx.x % CH) * 8;
-    float sc[8], sh[8], mu[8], is[8], c1[8], c2[8];
+    float sc[8], sh[8], mu[8], is[8], c1[8], c2[8], dm[8];
     loadf8(a.scale + c8, sc);
     loadf8(a.shift + c8, sh);
     loadf8(a.mean + c8, mu);
@@ -181,6 +185,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(ActBwdArgs a) {
     if (PHASE == 1) {
         loadf8(a.coef + c8, c1);
         loadf8(a.coef + a.C + c8, c2);
+        if (a.dy_keep) {
+            float kp[8];
+            loadf8(a.dy_keep + c8, kp);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dm[i] = kp[i] != 0.f ? sc[i] : 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dm[i] = sc[i];
+        }
     }
     float sb[8], sg[8];
 #pragma unroll
@@ -264,7 +277,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(ActBwdArgs a) {
                     sb[i] += gz;
                     sg[i] += gz * xh;
                 } else {
-                    out[i] = sc[i] * (gz - c1[i] - xh * c2[i]);
+                    out[i] = dm[i] * (gz - c1[i] - xh * c2[i]);
                 }
             }
             if (PHASE == 1) store8(a.dy + pad_off(b, hh[k], ww[k], a.H, a.W, a.dy_ld) + a.dy_choff + c8, out);
@@ -338,7 +351,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, int
         if (ld == 4) {  // stem image: 3 channels + one zero, one 8-byte store per pixel
             h4_t q;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) q[i] = (i < nc) ? (half_t)(s[i * HW] * mul) : (half_t)0.f;
+            for (int i = 0; i < 4; ++i) q[i] = (i < nc) ? sat_half(s[i * HW] * mul) : (half_t)0.f;
             *(h4_t*)d = q;
         } else if (nc == 8) {
             float v[8];
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, int
             for (int i = 0; i < 8; ++i) v[i] = s[i * HW] * mul;
             store8(d, v);
         } else {
-            for (int i = 0; i < nc; ++i) d[i] = (half_t)(s[i * HW] * mul);
+            for (int i = 0; i < nc; ++i) d[i] = sat_half(s[i * HW] * mul);
         }
     }
 }
@@ -442,6 +455,7 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
     a.slab = (float*)workspace;
     float* coef = (float*)workspace + (size_t)kBwdBlocks * 2 * d->C;
     a.coef = coef;
+    a.dy_keep = d->dy_keep;
     a.B = d->B, a.H = d->H, a.W = d->W, a.C = d->C;
     a.y_ld = d->y_ld, a.y_choff = d->y_choff, a.g_ld = d->g_ld, a.g_choff = d->g_choff;
     a.g2_ld = d->g2_ld, a.g2_choff = d->g2_choff, a.dy_ld = d->dy_ld, a.dy_choff = d->dy_choff;

@@ -185,7 +185,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BN >= 128 ? 2 : (BN >=
                             v = v * sc + sh;
                             v = v > 0.f ? v : v * a.slope;
                         }
-                        half_t hv = (half_t)v;
+                        half_t hv = (half_t)fminf(fmaxf(v, -65504.f), 65504.f);  // saturate, never inf
                         ct[row * BN + col] = hv;
                         if (a.stats) {
                             float fv = (mt * BM + row < a.M) ? (float)hv : 0.f;

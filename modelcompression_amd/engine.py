@@ -223,6 +223,7 @@ class Engine:
             wbytes = max(wbytes, ops.wgrad_workspace_bytes(g))
             lay.cout_p = ops.round_up(lay.cout, 32)
             lay.dy = ops.alloc_padded(B, lay.H, lay.W, lay.cout_p, dev)
+            lay.keep, lay.keep_key = None, None
             lay.gin = None
             if lay.li > 0:
                 lay.gin = torch.empty(lay.M * lay.tin.ld, dtype=ops.HALF, device=dev)
@@ -281,6 +282,11 @@ class Engine:
                 raise McamdError("conv weights must be contiguous fp32 (master copy)")
             mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
             ops.pack_weights(lay.geom, w, mask, True, lay.wd is not None, lay.wp, lay.wd)
+            # filters whose mask is entirely zero: their dY is never needed (sparse-masked backward)
+            key = None if mask is None else (mask.data_ptr(), mask._version)
+            if key != lay.keep_key:          # masks are static during retraining: computed once
+                lay.keep = (mask.reshape(mask.shape[0], -1).amax(1) != 0).float() if mask is not None else None
+                lay.keep_key = key
         self._packed_sig = sig
         self.model._weights_dirty = False
 
@@ -336,7 +342,7 @@ class Engine:
                 ops.bn_act_bwd(self.B, lay.H, lay.W, lay.cout, lay.y, lay.cout, 0, lay.scale, lay.shift, lay.mean,
                                lay.invstd, lay.slope, lay.mode, cons.gin, cons.tin.ld, t.choff, lay.dy, lay.cout_p, 0,
                                gmap[id(lay.bn.weight)], gmap[id(lay.bn.bias)], S, g2, g2_ld or 0, g2_choff or 0,
-                               self.bwd_ws)
+                               self.bwd_ws, lay.keep)
             mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
             dbias = gmap[id(lay.conv.bias)] if lay.conv.bias is not None else None
             self._timed('wgrad', lay, ops.conv_wgrad, lay.geom, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,

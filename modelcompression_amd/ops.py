@@ -144,7 +144,7 @@ def bn_act_fwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, slope, mode, dst, ds
 
 
 def bn_act_bwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, mean, invstd, slope, mode, g, g_ld, g_choff, dy, dy_ld,
-               dy_choff, dgamma, dbeta, grad_scale=1.0, g2=None, g2_ld=0, g2_choff=0, workspace=None):
+               dy_choff, dgamma, dbeta, grad_scale=1.0, g2=None, g2_ld=0, g2_choff=0, workspace=None, dy_keep=None):
     d = ActBwdDesc()
     d.B, d.H, d.W, d.C = B, H, W, C_
     d.y, d.y_ld, d.y_choff = y.data_ptr(), y_ld, y_choff
@@ -157,6 +157,7 @@ def bn_act_bwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, mean, invstd, slope,
     d.dgamma = dgamma.data_ptr() if dgamma is not None else None
     d.dbeta = dbeta.data_ptr() if dbeta is not None else None
     d.grad_scale = grad_scale
+    d.dy_keep = dy_keep.data_ptr() if dy_keep is not None else None
     need = int(L.lib().mcamd_bn_act_bwd_workspace_bytes(C.byref(d)))
     if workspace is None:
         workspace = torch.empty(need, dtype=torch.uint8, device=y.device)

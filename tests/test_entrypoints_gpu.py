@@ -1,0 +1,41 @@
+"""The train / predict entry points end to end on the GPU (synthetic data: VOC is not on disk)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from modelcompression_amd import YOLOV2_VOC_CFG  # noqa: E402
+from modelcompression_amd.train import YOLOv2Train  # noqa: E402
+from modelcompression_amd.predict import PASCALVOCEval  # noqa: E402
+from modelcompression_amd.pruning.weightPruning.utils import prune_rate  # noqa: E402
+
+
+@pytest.mark.parametrize("method,perc", [("weight", 80.0), ("filter", 40.0)])
+def test_prune_and_retrain_one_epoch(dev, tmp_path, method, perc):
+    t = YOLOv2Train()
+    model = t.train('', '', '', str(tmp_path / "log"), str(tmp_path / "val"), str(tmp_path / "pkl"), 'p_',
+                    YOLOV2_VOC_CFG, '', 8, 10, pruning_perc=perc, pruning_method=method,
+                    MAX_EPOCHS=1, SYNTHETIC_SAMPLES=16)
+    rate = prune_rate(model, verbose=False)
+    assert rate > (75.0 if method == "weight" else 10.0)       # pruned weights stayed zero through SGD (40% of the FILTERS is ~16% of the weights here)
+    final = [f for f in os.listdir(tmp_path / "log") if f.endswith(".weights")]
+    assert len(final) == 1 and os.path.getsize(tmp_path / "log" / final[0]) == 202704260
+    for p in model.parameters():
+        assert torch.isfinite(p).all()
+
+
+def test_predict_plumbing(dev, tmp_path):
+    from modelcompression_amd import nets
+    from modelcompression_amd.synthetic import init_synthetic
+    m = init_synthetic(nets.Darknet(YOLOV2_VOC_CFG), 0).to(dev)
+    ev = PASCALVOCEval(m, YOLOV2_VOC_CFG, '', None, '', '', str(tmp_path / "det"), 'comp4_det_test_', str(tmp_path / "pkl"))
+    ev.predict(BATCH_SIZE=4, CONF_THRESH=0.3)
+    files = os.listdir(tmp_path / "det")
+    assert len(files) == 20 and ev.num_detections >= 0
+
+
+def test_smoke_entry(dev):
+    import __graft_entry__ as g
+    g.smoke()
