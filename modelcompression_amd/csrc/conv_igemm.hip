@@ -267,7 +267,7 @@ static TileCfg pick_tile(int n, int cin_tap) {
             best = bn;
         }
     t.bn = best;
-    int want_bk = env_int("MCAMD_BK", 32);
+    int want_bk = env_int("MCAMD_BK", 64);
     t.bk = (want_bk == 64 && cin_tap % 64 == 0) ? 64 : 32;
     return t;
 }

@@ -16,7 +16,16 @@
 #include <stdlib.h>
 
 
-__device__ __forceinline__ h8_t tr_frag(const char* tile, int rowbytes, int s, int colbase, int lane) {
+// 16-byte-chunk XOR swizzle of an LDS row of RB bytes so that the 4 rows one ds_read_b64_tr_b16
+// half-wave touches land on different banks (256-byte rows alias all 4 rows, 128-byte rows alias
+// rows q and q+2; 64-byte rows do not alias).  Applied on the DMA source and on the read.
+template <int RB>
+__device__ __forceinline__ int tr_swz(int row) {
+    return RB == 256 ? ((row & 3) << 2) : (RB == 128 ? (((row >> 1) & 1) << 2) : 0);
+}
+
+template <int RB>
+__device__ __forceinline__ h8_t tr_frag(const char* tile, int s, int colbase, int lane) {
     // Fragment for a 32x32x16 MFMA operand whose k index is the LDS row:
     // lane l gets T[k = 16*s + 8*(l>>5) + j][colbase + (l&31)], j = 0..7.
     // ds_read_b64_tr_b16: within each 16-lane group, lane 4q+p supplies the address of row q,
@@ -24,8 +33,11 @@ __device__ __forceinline__ h8_t tr_frag(const char* tile, int rowbytes, int s, i
     const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
     const int kb = 16 * s + 8 * (g >> 1);
     const int cb = colbase + 16 * (g & 1);
-    const char* p0 = tile + (kb + q) * rowbytes + (cb + 4 * p) * 2;
-    const char* p1 = p0 + 4 * rowbytes;
+    const int row = kb + q;
+    const int off = (cb + 4 * p) * 2;                                  // byte offset inside the row
+    const int soff = (((off >> 4) ^ tr_swz<RB>(row)) << 4) | (off & 15);  // row+4 has the same swizzle
+    const char* p0 = tile + row * RB + soff;
+    const char* p1 = p0 + 4 * RB;
     union {
         fp16x4_t h[2];
         h8_t v;
@@ -39,68 +51,84 @@ struct PixState {
     int b, h, w, m;
 };
 
-template <int TMo, int TNc>
-__global__ __launch_bounds__((TMo >= 64 ? 2 : 1) * (TNc >= 64 ? 2 : 1) * 64) void wgrad_kernel(WgradArgs a) {
-    constexpr int WAVES_M = TMo >= 64 ? 2 : 1, WAVES_N = TNc >= 64 ? 2 : 1;
-    constexpr int NT = WAVES_M * WAVES_N * 64;
-    constexpr int WMo = TMo / WAVES_M, WNc = TNc / WAVES_N;
-    constexpr int TI = WMo / 32, TJ = WNc / 32;
+// Workgroup = 4 waves; it owns dW[TMo filters][TAPS taps][TNc input channels] for one pixel split.
+// The dY tile (KP pixels x TMo) is staged once per step and shared by all TAPS X tiles
+// (KP pixels x TNc each, shifted by the tap), so dY -- the big operand of the early layers -- is
+// read TAPS times less often.  Wave w owns filter block i = w % NI (NI = TMo/32) and every
+// WPI-th (tap, cin-block) task: one A fragment per k16 step feeds all its MFMAs.
+template <int TMo, int TNc, int TAPS, int KP>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    constexpr int NT = 256;
+    constexpr int NI = TMo / 32, WPI = 4 / NI, NJ = TNc / 32;
+    constexpr int NT2 = TAPS * NJ, NACC = (NT2 + WPI - 1) / WPI;
+    constexpr int RBA = TMo * 2, RBB = TNc * 2;
     constexpr int A_CH = TMo / 8, B_CH = TNc / 8;
-    constexpr int A_SLOTS = 32 * A_CH, B_SLOTS = 32 * B_CH;
+    constexpr int A_SLOTS = KP * A_CH, B_SLOTS = TAPS * KP * B_CH;
     constexpr int A_IT = (A_SLOTS + NT - 1) / NT, B_IT = (B_SLOTS + NT - 1) / NT;
     constexpr int STAGE_BYTES = (A_SLOTS + B_SLOTS) * 16;
     static_assert(A_SLOTS % 64 == 0 && B_SLOTS % 64 == 0, "whole waves per DMA instruction");
+    static_assert(NI == 1 || NI == 2 || NI == 4, "TMo in {32, 64, 128}");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int wi = wave % NI, part = wave / NI;
 
-    const int per_o = a.ntaps * a.n_ctiles;
-    const int ot = blockIdx.x / per_o;
-    const int rem = blockIdx.x - ot * per_o;
-    const int tap = rem / a.n_ctiles;
-    const int ct = rem - tap * a.n_ctiles;
-    const int split = blockIdx.y;
+    // XCD-aware order: work items are numbered split-major (all tiles of a split stream the same
+    // dY / X pixel range); blocks are dealt round-robin to the 8 XCDs, so XCD x takes the
+    // contiguous chunk [x*chunk, (x+1)*chunk) and neighbouring items share its L2.
+    const int ntiles = a.n_otiles * a.n_tapgroups * a.n_ctiles;
+    const int total_items = ntiles * a.nsplit;
+    const int chunk = (total_items + 7) >> 3;
+    const int item = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || item >= total_items) return;
+    const int split = item / ntiles;
+    const int tile = item - split * ntiles;
+    const int per_o = a.n_tapgroups * a.n_ctiles;
+    const int ot = tile / per_o;
+    const int rem = tile - ot * per_o;
+    const int tg = rem / a.n_ctiles;
+    const int ct = rem - tg * a.n_ctiles;
+    const int t0 = tg * TAPS;
     const int k0 = split * a.pix_per_split;
     int k1 = k0 + a.pix_per_split;
     if (k1 > a.M) k1 = a.M;
-    const int nsteps = (k1 - k0 + 31) / 32;
-    const int x_tap_off = a.tap_off[tap] + a.x_off + ct * TNc;
+    const int nsteps = k1 > k0 ? (k1 - k0 + KP - 1) / KP : 0;
     const int dy_col_off = ot * TMo;
 
-    // Pixel state per DMA slot (row of the 32-pixel chunk this thread fetches).
     PixState pa[A_IT], pb[B_IT];
     int cha[A_IT], chb[B_IT];
+    auto init_pix = [&](PixState& p, int row) {
+        int m = k0 + row;
+        int mm = m < a.M ? m : 0;
+        p.m = m;
+        p.b = mm / a.HW;
+        int r2 = mm - p.b * a.HW;
+        p.h = r2 / a.W;
+        p.w = r2 - p.h * a.W;
+    };
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
         int slot = it * NT + tid;
-        int row = slot / A_CH;
-        cha[it] = (slot - row * A_CH) * 8;
-        int m = k0 + row;
-        int mm = m < a.M ? m : 0;
-        pa[it].m = m;
-        pa[it].b = mm / a.HW;
-        int r2 = mm - pa[it].b * a.HW;
-        pa[it].h = r2 / a.W;
-        pa[it].w = r2 - pa[it].h * a.W;
+        int row = (slot / A_CH) % KP;
+        cha[it] = ((slot % A_CH) ^ tr_swz<RBA>(row)) * 8;   // source chunk for this LDS slot
+        init_pix(pa[it], row);
     }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
         int slot = it * NT + tid;
-        int row = slot / B_CH;
-        chb[it] = (slot - row * B_CH) * 8;
-        int m = k0 + row;
-        int mm = m < a.M ? m : 0;
-        pb[it].m = m;
-        pb[it].b = mm / a.HW;
-        int r2 = mm - pb[it].b * a.HW;
-        pb[it].h = r2 / a.W;
-        pb[it].w = r2 - pb[it].h * a.W;
+        int tapl = slot / (KP * B_CH);
+        if (tapl > TAPS - 1) tapl = TAPS - 1;               // slots past the tile are never issued
+        int r2 = slot - tapl * (KP * B_CH);
+        int row = (r2 / B_CH) % KP;
+        chb[it] = ((r2 % B_CH) ^ tr_swz<RBB>(row)) * 8 + a.tap_off[t0 + tapl] + a.x_off + ct * TNc;
+        init_pix(pb[it], row);
     }
+    const int qkp = KP / a.W, rkp = KP - qkp * a.W;   // KP pixels = qkp rows + rkp pixels
     auto advance = [&](PixState& p) {
-        p.m += 32;
-        p.w += 32;
-        while (p.w >= a.W) {
+        p.m += KP;
+        p.w += rkp;
+        p.h += qkp;
+        if (p.w >= a.W) {
             p.w -= a.W;
             p.h += 1;
         }
@@ -110,13 +138,11 @@ __global__ __launch_bounds__((TMo >= 64 ? 2 : 1) * (TNc >= 64 ? 2 : 1) * 64) voi
         }
     };
 
-    f32x16_t acc[TI][TJ];
+    f32x16_t acc[NACC];
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
+    for (int i = 0; i < NACC; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     auto stage = [&](int buf) {
         char* sa = smem + buf * STAGE_BYTES;
@@ -142,9 +168,9 @@ __global__ __launch_bounds__((TMo >= 64 ? 2 : 1) * (TNc >= 64 ? 2 : 1) * 64) voi
                 const half_t* src;
                 if (pb[it].m < k1)
                     src = a.x + (long long)pb[it].b * a.x_img_stride + (long long)pb[it].h * a.x_row_stride +
-                          (long long)pb[it].w * a.x_ld + x_tap_off + chb[it];
+                          (long long)pb[it].w * a.x_ld + chb[it];
                 else
-                    src = a.x + a.x_off + chb[it];  // any finite data; its dY partner is zero
+                    src = a.x + a.x_off;  // any finite data; its dY partner is zero
                 glds16(src, sb + wslot * 16);
             }
             advance(pb[it]);
@@ -159,60 +185,121 @@ __global__ __launch_bounds__((TMo >= 64 ? 2 : 1) * (TNc >= 64 ? 2 : 1) * 64) voi
         const char* sa = smem + (st & 1) * STAGE_BYTES;
         const char* sb = sa + A_SLOTS * 16;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            h8_t af[TI], bf[TJ];
+        for (int s = 0; s < KP / 16; ++s) {
+            const h8_t af = tr_frag<RBA>(sa, s, wi * 32, lane);
 #pragma unroll
-            for (int i = 0; i < TI; ++i) af[i] = tr_frag(sa, TMo * 2, s, wm * WMo + i * 32, lane);
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) bf[j] = tr_frag(sb, TNc * 2, s, wn * WNc + j * 32, lane);
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            for (int idx = 0; idx < NACC; ++idx) {
+                const int q = part + WPI * idx;     // (tap, cin-block) task of this wave
+                if (q < NT2) {
+                    const int tapl = q / NJ, jn = q - tapl * NJ;
+                    const h8_t bf = tr_frag<RBB>(sb + tapl * (KP * RBB), s, jn * 32, lane);
+                    acc[idx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[idx], 0, 0, 0);
+                }
+            }
         }
     }
 
     float* out = a.slab + (long long)split * a.rows_pad * a.ktot;
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j)
+    for (int idx = 0; idx < NACC; ++idx) {
+        const int q = part + WPI * idx;
+        if (q < NT2) {
+            const int tapl = q / NJ, jn = q - tapl * NJ;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int n = ot * TMo + wm * WMo + i * 32 + mfma32_row(r, lane);
-                int k = tap * a.cin_tap + ct * TNc + wn * WNc + j * 32 + (lane & 31);
-                out[(long long)n * a.ktot + k] = acc[i][j][r];
+                int n = ot * TMo + wi * 32 + mfma32_row(r, lane);
+                int k = (t0 + tapl) * a.cin_tap + ct * TNc + jn * 32 + (lane & 31);
+                out[(long long)n * a.ktot + k] = acc[idx][r];
             }
-}
-
-// Sum the split slabs in order, apply mask and 1/grad_scale, write fp32 OIHW.
-// grid (ceil(Cin/256), Cout), 256 threads; KK = ksize*ksize.
-__global__ void wgrad_finish_kernel(const float* slab, int nsplit, int rows_pad, int ktot, int cin_tap, int stem,
-                                    int Cout, int Cin, int KK, const float* mask, float inv_scale, float* dw) {
-    __shared__ float buf[256 * 9];
-    const int n = blockIdx.y;
-    const int c0 = blockIdx.x * 256;
-    const int c = c0 + threadIdx.x;
-    const long long split_stride = (long long)rows_pad * ktot;
-    if (c < Cin) {
-        for (int t = 0; t < KK; ++t) {
-            int kidx = stem ? (t / 3) * 32 + (t % 3) * 4 + c : t * cin_tap + c;
-            const float* p = slab + (long long)n * ktot + kidx;
-            float v = 0.f;
-            for (int s = 0; s < nsplit; ++s) v += p[s * split_stride];
-            buf[threadIdx.x * KK + t] = v;
         }
     }
-    __syncthreads();
-    int cnt = Cin - c0;
-    if (cnt > 256) cnt = 256;
-    const long long base = ((long long)n * Cin + c0) * KK;
-    for (int e = threadIdx.x; e < cnt * KK; e += 256) {
-        float v = buf[e] * inv_scale;
-        if (mask) v *= mask[base + e];
-        dw[base + e] = v;
+}
+
+// Sum the split slabs, apply mask and 1/grad_scale, write fp32 OIHW.  Deterministic: thread
+// (item, sg) sums the splits s = sg, sg+SG, ... in order, the SG partial sums are combined in
+// order through LDS.  SG grows with the split count so narrow layers (few weights, ~1000 pixel
+// splits) still expose enough parallel loads.
+// Vector form (Cin % 4 == 0): an item = 4 consecutive input channels of one filter = 4*KK
+// contiguous OIHW floats; per tap it sums float4 slab reads (coalesced across the block) and the
+// transposition [tap][c] -> [c][tap] happens in registers.
+template <int KK, int SG>
+__global__ __launch_bounds__(256) void wgrad_finish_vec_kernel(const float* slab, int nsplit, int rows_pad, int ktot,
+                                                               int cin_tap, int Cout, int Cin, const float* mask,
+                                                               float inv_scale, float* dw) {
+    constexpr int OPB = 256 / SG;  // items per block
+    __shared__ f32x4_t red[SG > 1 ? SG * OPB * KK : 1];
+    const int c4n = Cin >> 2;
+    const long long total = (long long)Cout * c4n;
+    const long long split_stride = (long long)rows_pad * ktot;
+    const int o = threadIdx.x % OPB, sg = threadIdx.x / OPB;
+    const long long idx = (long long)blockIdx.x * OPB + o;
+    const bool live = idx < total;
+    const int n = live ? (int)(idx / c4n) : 0;
+    const int c = live ? (int)(idx - (long long)n * c4n) * 4 : 0;
+    f32x4_t acc[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+        f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            const float* p = slab + (long long)n * ktot + t * cin_tap + c;
+            for (int s = sg; s < nsplit; s += SG) v += *(const f32x4_t*)(p + s * split_stride);
+        }
+        acc[t] = v;
     }
+    if (SG > 1) {
+#pragma unroll
+        for (int t = 0; t < KK; ++t) red[(sg * OPB + o) * KK + t] = acc[t];
+        __syncthreads();
+        if (sg != 0) return;
+#pragma unroll
+        for (int t = 0; t < KK; ++t) {
+            f32x4_t v = acc[t];
+            for (int g = 1; g < SG; ++g) v += red[(g * OPB + o) * KK + t];
+            acc[t] = v;
+        }
+    }
+    if (!live) return;
+    float out[4 * KK];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int t = 0; t < KK; ++t) out[jj * KK + t] = acc[t][jj] * inv_scale;
+    const long long base = ((long long)n * Cin + c) * KK;   // multiple of 4 floats: 16-byte aligned
+#pragma unroll
+    for (int e = 0; e < KK; ++e) {
+        f32x4_t ov = {out[4 * e], out[4 * e + 1], out[4 * e + 2], out[4 * e + 3]};
+        if (mask) ov *= *(const f32x4_t*)(mask + base + 4 * e);
+        *(f32x4_t*)(dw + base + 4 * e) = ov;
+    }
+}
+
+// Scalar form for any Cin (stem: Cin = 3): an item = one OIHW element.
+template <int SG>
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* slab, int nsplit, int rows_pad, int ktot,
+                                                           int cin_tap, int stem, int Cout, int Cin, int KK,
+                                                           const float* mask, float inv_scale, float* dw) {
+    constexpr int OPB = 256 / SG;
+    __shared__ float red[SG * OPB];
+    const long long total = (long long)Cout * Cin * KK;
+    const long long split_stride = (long long)rows_pad * ktot;
+    const int o = threadIdx.x % OPB, sg = threadIdx.x / OPB;
+    const long long e = (long long)blockIdx.x * OPB + o;
+    float v = 0.f;
+    if (e < total) {
+        const int n = (int)(e / (Cin * KK));
+        const int r = (int)(e - (long long)n * Cin * KK);
+        const int c = r / KK, t = r - c * KK;
+        const int kidx = stem ? (t / 3) * 32 + (t % 3) * 4 + c : t * cin_tap + c;
+        const float* p = slab + (long long)n * ktot + kidx;
+        for (int s2 = sg; s2 < nsplit; s2 += SG) v += p[s2 * split_stride];
+    }
+    red[sg * OPB + o] = v;
+    __syncthreads();
+    if (sg != 0 || e >= total) return;
+    for (int g = 1; g < SG; ++g) v += red[g * OPB + o];
+    v *= inv_scale;
+    if (mask) v *= mask[e];
+    dw[e] = v;
 }
 
 // dbias[n] = sum over every padded pixel of dy[pixel][choff + n] / grad_scale (halo rows are zero).
@@ -238,26 +325,48 @@ static int pick_t(int n) {  // largest of 128/64/32 dividing round_up(n, 32)
     return 32;
 }
 
-
 static int env_int_w(const char* name, int dflt) {
     const char* s = getenv(name);
     return s && *s ? atoi(s) : dflt;
+}
+
+// taps per workgroup: as many as keep <= 6 accumulator blocks per wave
+static int pick_taps(int tmo, int tnc, int ntaps) {
+    if (ntaps == 1) return 1;
+    const int ni = tmo / 32, wpi = 4 / ni, nj = tnc / 32;
+    const int cands[3] = {9, 3, 1};
+    for (int c = 0; c < 3; ++c) {
+        int t = cands[c];
+        if (t > ntaps || ntaps % t) continue;
+        if ((t * nj + wpi - 1) / wpi <= 6) return t;
+    }
+    return 1;
+}
+
+static int pick_kp(int tmo, int tnc, int taps) {
+    const int budget = env_int_w("MCAMD_WGRAD_STAGE_KB", 24) * 1024;
+    for (int kp = 128; kp > 32; kp /= 2)
+        if (kp * 2 * (tmo + taps * tnc) <= budget) return kp;
+    return 32;
 }
 
 WgradPlan mcamd_wgrad_plan(long long M, int cout, int cin_tap, int ntaps) {
     WgradPlan p;
     p.tmo = pick_t(cout);
     p.tnc = pick_t(cin_tap);
+    p.taps = pick_taps(p.tmo, p.tnc, ntaps);
+    p.kp = pick_kp(p.tmo, p.tnc, p.taps);
     p.rows_pad = round_up_int(cout, p.tmo);
     p.n_otiles = p.rows_pad / p.tmo;
     p.n_ctiles = cin_tap / p.tnc;
-    long long tiles = (long long)p.n_otiles * ntaps * p.n_ctiles;
+    p.n_tapgroups = ntaps / p.taps;
+    long long tiles = (long long)p.n_otiles * p.n_tapgroups * p.n_ctiles;
     long long target = env_int_w("MCAMD_WGRAD_WGS", 1024);
     long long ns = (target + tiles - 1) / tiles;
-    long long max_by_work = (M + 255) / 256;  // at least 8 steps of 32 pixels per split
+    long long max_by_work = (M + 8 * p.kp - 1) / (8 * p.kp);  // at least 8 steps per split
     if (ns > max_by_work) ns = max_by_work;
     if (ns < 1) ns = 1;
-    long long pps = ((M + ns - 1) / ns + 31) / 32 * 32;
+    long long pps = ((M + ns - 1) / ns + p.kp - 1) / p.kp * p.kp;
     ns = (M + pps - 1) / pps;
     p.nsplit = (int)ns;
     p.pix_per_split = (int)pps;
@@ -265,32 +374,82 @@ WgradPlan mcamd_wgrad_plan(long long M, int cout, int cin_tap, int ntaps) {
     return p;
 }
 
-template <int TMo, int TNc>
-static void launch_w(const WgradArgs& a, int gx, int gy, hipStream_t st) {
-    constexpr int NT = (TMo >= 64 ? 2 : 1) * (TNc >= 64 ? 2 : 1) * 64;
-    size_t lds = 2 * (size_t)(32 * (TMo / 8) + 32 * (TNc / 8)) * 16;
-    hipLaunchKernelGGL((wgrad_kernel<TMo, TNc>), dim3(gx, gy), dim3(NT), lds, st, a);
+template <int TMo, int TNc, int TAPS, int KP>
+static void launch_w(const WgradArgs& a, int grid, hipStream_t st) {
+    size_t lds = 2 * (size_t)(KP * (TMo / 8) + TAPS * KP * (TNc / 8)) * 16;
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute((const void*)wgrad_kernel<TMo, TNc, TAPS, KP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_kernel<TMo, TNc, TAPS, KP>), dim3(grid), dim3(256), lds, st, a);
 }
 
 int mcamd_wgrad_launch(WgradArgs& a, const WgradPlan& p, hipStream_t st) {
     a.rows_pad = p.rows_pad;
     a.n_ctiles = p.n_ctiles;
+    a.n_otiles = p.n_otiles;
+    a.n_tapgroups = p.n_tapgroups;
+    a.nsplit = p.nsplit;
     a.pix_per_split = p.pix_per_split;
-    int gx = p.n_otiles * a.ntaps * p.n_ctiles, gy = p.nsplit;
-#define W_CASE(TM_, TN_) \
-    if (p.tmo == TM_ && p.tnc == TN_) launch_w<TM_, TN_>(a, gx, gy, st);
-    W_CASE(128, 128) W_CASE(128, 64) W_CASE(128, 32) W_CASE(64, 128) W_CASE(64, 64) W_CASE(64, 32) W_CASE(32, 128)
-    W_CASE(32, 64) W_CASE(32, 32)
+    const int tiles = p.n_otiles * p.n_tapgroups * p.n_ctiles;
+    const int grid = round_up_int(tiles * p.nsplit, 8);
+    bool done = false;
+#define W_CASE(TM_, TN_, TP_, KP_)                                              \
+    if (!done && p.tmo == TM_ && p.tnc == TN_ && p.taps == TP_ && p.kp == KP_) { \
+        launch_w<TM_, TN_, TP_, KP_>(a, grid, st);                              \
+        done = true;                                                            \
+    }
+#define W_KPS(TM_, TN_, TP_) W_CASE(TM_, TN_, TP_, 32) W_CASE(TM_, TN_, TP_, 64) W_CASE(TM_, TN_, TP_, 128)
+    W_KPS(32, 32, 9) W_KPS(32, 32, 3) W_KPS(32, 32, 1)
+    W_KPS(32, 64, 9) W_KPS(32, 64, 3) W_KPS(32, 64, 1)
+    W_KPS(32, 128, 3) W_KPS(32, 128, 1)
+    W_KPS(64, 32, 9) W_KPS(64, 32, 3) W_KPS(64, 32, 1)
+    W_KPS(64, 64, 3) W_KPS(64, 64, 1)
+    W_KPS(64, 128, 3) W_KPS(64, 128, 1)
+    W_KPS(128, 32, 3) W_KPS(128, 32, 1)
+    W_KPS(128, 64, 3) W_KPS(128, 64, 1)
+    W_KPS(128, 128, 1)
+#undef W_KPS
 #undef W_CASE
+    if (!done) {
+        mcamd_set_error("wgrad: no kernel instance for tile %dx%d taps %d kp %d", p.tmo, p.tnc, p.taps, p.kp);
+        return MCAMD_EINVAL;
+    }
     MCAMD_LAUNCH_CHECK("wgrad");
     return MCAMD_OK;
 }
 
+template <int KK>
+static void launch_finish_vec(int sg, long long total, const float* slab, const WgradPlan& p, int ktot, int cin_tap, int Cout,
+                              int Cin, const float* mask, float inv_scale, float* dw, hipStream_t st) {
+#define F_CASE(SG_)                                                                                               \
+    hipLaunchKernelGGL((wgrad_finish_vec_kernel<KK, SG_>), dim3((unsigned)((total + 256 / SG_ - 1) / (256 / SG_))), \
+                       dim3(256), 0, st, slab, p.nsplit, p.rows_pad, ktot, cin_tap, Cout, Cin, mask, inv_scale, dw)
+    if (sg == 1) F_CASE(1);
+    else if (sg == 8) F_CASE(8);
+    else F_CASE(32);
+#undef F_CASE
+}
+
 int mcamd_wgrad_finish_launch(const float* slab, const WgradPlan& p, int ktot, int cin_tap, int stem, int Cout, int Cin,
                               int ksize, const float* mask, float inv_scale, float* dw, hipStream_t st) {
-    dim3 grid((Cin + 255) / 256, Cout);
-    hipLaunchKernelGGL(wgrad_finish_kernel, grid, dim3(256), 0, st, slab, p.nsplit, p.rows_pad, ktot, cin_tap, stem,
-                       Cout, Cin, ksize * ksize, mask, inv_scale, dw);
+    const int sg = p.nsplit <= 4 ? 1 : (p.nsplit <= 64 ? 8 : 32);
+    if (!stem && Cin % 4 == 0 && (ksize == 1 || ksize == 3)) {
+        long long total = (long long)Cout * (Cin / 4);
+        if (ksize == 3) launch_finish_vec<9>(sg, total, slab, p, ktot, cin_tap, Cout, Cin, mask, inv_scale, dw, st);
+        else launch_finish_vec<1>(sg, total, slab, p, ktot, cin_tap, Cout, Cin, mask, inv_scale, dw, st);
+    } else {
+        long long total = (long long)Cout * Cin * ksize * ksize;
+#define S_CASE(SG_)                                                                                                  \
+    hipLaunchKernelGGL((wgrad_finish_kernel<SG_>), dim3((unsigned)((total + 256 / SG_ - 1) / (256 / SG_))), dim3(256), 0, \
+                       st, slab, p.nsplit, p.rows_pad, ktot, cin_tap, stem, Cout, Cin, ksize * ksize, mask, inv_scale, dw)
+        if (sg == 1) S_CASE(1);
+        else if (sg == 8) S_CASE(8);
+        else S_CASE(32);
+#undef S_CASE
+    }
     MCAMD_LAUNCH_CHECK("wgrad_finish");
     return MCAMD_OK;
 }

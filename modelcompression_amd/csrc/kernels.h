@@ -40,11 +40,12 @@ struct WgradArgs {
     int ktot, cin_tap, ntaps;
     int tap_off[9];
     int n_ctiles;     // cin tiles per tap
+    int n_otiles, n_tapgroups, nsplit;
     int pix_per_split;
 };
 
 struct WgradPlan {
-    int tmo, tnc, rows_pad, n_otiles, n_ctiles, nsplit, pix_per_split;
+    int tmo, tnc, taps, kp, rows_pad, n_otiles, n_ctiles, n_tapgroups, nsplit, pix_per_split;
     size_t bytes;
 };
 
