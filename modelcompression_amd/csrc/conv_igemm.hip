@@ -31,8 +31,15 @@ __device__ __forceinline__ int swz(int row) {
     return CPR == 4 ? ((row >> 2) & 3) : ((row >> 1) & 7);
 }
 
-template <int BM, int BN, int WM, int WN, int BK>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BN >= 128 ? 2 : (BN >= 64 ? 3 : 4))) void igemm_kernel(IgemmArgs a) {
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int NSTAGE>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64,
+                              ((BM / WM) * (BN / WN) >= 8 ? 2 : (BN >= 128 ? (NSTAGE * BK <= 96 ? 3 : 2) : (BN >= 64 ? 3 : 4))))
+void igemm_kernel(IgemmArgs a) {
     constexpr int WAVES_N = BN / WN;
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     constexpr int CPR = BK / 8;
@@ -40,15 +47,37 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BN >= 128 ? 2 : (BN >=
     constexpr int A_IT = (A_SLOTS + NT - 1) / NT, B_IT = (B_SLOTS + NT - 1) / NT;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int STAGE_BYTES = (A_SLOTS + B_SLOTS) * 16;
+    // DMA instructions EVERY wave issues per K-chunk (waves may issue one more when the tile is not a
+    // multiple of the workgroup; counting the minimum only makes the counted waits stricter).
+    constexpr int DMIN = A_SLOTS / NT + B_SLOTS / NT;
     static_assert(A_SLOTS % 64 == 0 && B_SLOTS % 64 == 0, "whole waves per DMA instruction");
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4 && DMIN * (NSTAGE - 2) < 64, "vmcnt immediate range");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    // provably wave-uniform (readfirstlane): otherwise hipcc wraps every LDS-DMA in a waterfall loop
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int nt = blockIdx.y;
+    // XCD-aware order.  Work items (N tile, persistent M slot) are numbered N-major; blocks are dealt
+    // round-robin to the 8 XCDs, so XCD x takes the contiguous chunk [x*chunk, (x+1)*chunk): about one
+    // weight (B) tile per XCD stays resident in its 4 MB L2 while the activation tiles stream through.
+    // MCAMD_XCD_ORDER=1 selects the other orientation (all N tiles of an M slot on one XCD).
+    int nt, pslot;
+    if (a.xcd_order == 0) {
+        const int total_items = a.num_ntiles * a.num_pslots;
+        const int chunk = (total_items + 7) >> 3;
+        const int item = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+        if ((int)(blockIdx.x >> 3) >= chunk || item >= total_items) return;
+        nt = item / a.num_pslots;
+        pslot = item - nt * a.num_pslots;
+    } else {
+        const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+        nt = jb % a.num_ntiles;
+        pslot = (jb / a.num_ntiles) * 8 + xcd;
+        if (pslot >= a.num_pslots) return;
+    }
     const int nchunks = a.ktot / BK;
     const int cpt = a.cin_tap / BK;  // chunks per tap
 
@@ -66,7 +95,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BN >= 128 ? 2 : (BN >=
 #pragma unroll
     for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
 
-    for (int mt = blockIdx.x; mt < a.num_mtiles; mt += gridDim.x) {
+    for (int mt = pslot; mt < a.num_mtiles; mt += a.num_pslots) {
         // ---- per-tile A row bases (top-left tap of each output pixel, swizzled chunk) ----
         long long abase[A_IT];
 #pragma unroll
@@ -99,43 +128,67 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BN >= 128 ? 2 : (BN >=
             char* sb = sa + A_SLOTS * 16;
 #pragma unroll
             for (int it = 0; it < A_IT; ++it) {
-                int wslot = it * NT + (tid & ~63);
+                int wslot = it * NT + wave * 64;
                 if (wslot < A_SLOTS) glds16(a.x + abase[it] + koff, sa + wslot * 16);
             }
 #pragma unroll
             for (int it = 0; it < B_IT; ++it) {
-                int wslot = it * NT + (tid & ~63);
+                int wslot = it * NT + wave * 64;
                 if (wslot < B_SLOTS) glds16(a.w + bbase[it] + (long long)q * BK, sb + wslot * 16);
             }
         };
 
         __syncthreads();  // previous tile's epilogue has finished with the LDS
-        stage(0, 0);
-        for (int q = 0; q < nchunks; ++q) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();  // chunk q landed for every wave; every wave is done reading chunk q-1
-            if (q + 1 < nchunks) stage(q + 1, (q + 1) & 1);
-            const char* sa = smem + (q & 1) * STAGE_BYTES;
-            const char* sb = sa + A_SLOTS * 16;
+        // NSTAGE-deep LDS ring: chunks q+1 .. q+NSTAGE-2 stay in flight across the barrier while chunk q
+        // is multiplied (counted vmcnt + raw s_barrier: a __syncthreads() here would drain the DMAs).
 #pragma unroll
-            for (int s = 0; s < BK / 16; ++s) {
+        for (int p = 0; p < NSTAGE - 1; ++p)
+            if (p < nchunks) stage(p, p);
+        int sidx = 0;  // ring slot of chunk q
+        for (int q = 0; q < nchunks; ++q) {
+            int issued = q + NSTAGE - 1;
+            if (issued > nchunks) issued = nchunks;
+            const int inflight = issued - q - 1;  // chunks allowed to be still in flight
+            if (NSTAGE == 2 || inflight == 0) wait_vmcnt<0>();
+            else if (inflight == 1) wait_vmcnt<DMIN>();
+            else wait_vmcnt<(NSTAGE > 3 ? 2 * DMIN : DMIN)>();
+            __builtin_amdgcn_s_barrier();  // chunk q landed for every wave; every wave is done reading chunk q-1
+            if (q + NSTAGE - 1 < nchunks) {
+                int ns = sidx + NSTAGE - 1;
+                if (ns >= NSTAGE) ns -= NSTAGE;
+                stage(q + NSTAGE - 1, ns);
+            }
+            const char* sa = smem + sidx * STAGE_BYTES;
+            const char* sb = sa + A_SLOTS * 16;
+            sidx = sidx + 1 == NSTAGE ? 0 : sidx + 1;
+            // Fragment reads are software-pipelined: the ds_reads of k16 sub-step s+1 are issued before the
+            // MFMAs of sub-step s (two fragment sets), so LDS latency hides under the matrix pipe.
+            constexpr int KS = BK / 16;
+            h8_t af[2][TM], bf[2][TN];
+            auto load_frags = [&](int s, int set) {
                 const int chunk = 2 * s + (lane >> 5);
-                h8_t af[TM], bf[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     int row = wm * WM + i * 32 + (lane & 31);
-                    af[i] = *(const h8_t*)(sa + (row * CPR + (chunk ^ swz<CPR>(row))) * 16);
+                    af[set][i] = *(const h8_t*)(sa + (row * CPR + (chunk ^ swz<CPR>(row))) * 16);
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     int row = wn * WN + j * 32 + (lane & 31);
-                    bf[j] = *(const h8_t*)(sb + (row * CPR + (chunk ^ swz<CPR>(row))) * 16);
+                    bf[set][j] = *(const h8_t*)(sb + (row * CPR + (chunk ^ swz<CPR>(row))) * 16);
                 }
+            };
+            load_frags(0, 0);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (s + 1 < KS) load_frags(s + 1, (s + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this sub-step's MFMAs
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 
@@ -239,7 +292,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BN >= 128 ? 2 : (BN >=
             float v = 0.f;
 #pragma unroll
             for (int k = 0; k < BM / WM; ++k) v += red[(k * 2 + which) * BN + col];
-            a.stats[((long long)blockIdx.x * 2 + which) * a.stats_ld + nt * BN + col] = v;
+            a.stats[((long long)pslot * 2 + which) * a.stats_ld + nt * BN + col] = v;
         }
     }
 }
@@ -291,14 +344,20 @@ int mcamd_igemm_rows(long long M, int n, int cin_tap) {
     return p;
 }
 
-template <int BM, int BN, int WM, int WN, int BK>
+template <int BM, int BN, int WM, int WN, int BK, int NSTAGE>
 static void launch_one(const IgemmArgs& a, int rows, int ntiles, hipStream_t st) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     constexpr int STAGE_BYTES = (BM + BN) * (BK / 8) * 16;
-    size_t lds = 2 * STAGE_BYTES;
+    size_t lds = NSTAGE * STAGE_BYTES;
     if (lds < (size_t)BM * BN * 2) lds = (size_t)BM * BN * 2;
     if (lds < (size_t)(BM / WM) * 2 * BN * 4) lds = (size_t)(BM / WM) * 2 * BN * 4;
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BK>), dim3(rows, ntiles), dim3(NT), lds, st, a);
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, BK, NSTAGE>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BK, NSTAGE>), dim3(round_up_int(rows, 8) * ntiles + 8), dim3(NT), lds, st, a);
 }
 
 // a.* geometry fields must be filled by the caller; picks the tile and launches.
@@ -311,12 +370,33 @@ int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st) {
     int ntiles = (a.N + t.bn - 1) / t.bn;
     a.num_mtiles = mcamd_igemm_mtiles(a.M);
     int rows = mcamd_igemm_rows(a.M, a.N, a.cin_tap);
-    if (t.bn == 128 && t.bk == 32) launch_one<128, 128, 64, 64, 32>(a, rows, ntiles, st);
-    else if (t.bn == 128) launch_one<128, 128, 64, 64, 64>(a, rows, ntiles, st);
-    else if (t.bn == 64 && t.bk == 32) launch_one<128, 64, 64, 32, 32>(a, rows, ntiles, st);
-    else if (t.bn == 64) launch_one<128, 64, 64, 32, 64>(a, rows, ntiles, st);
-    else if (t.bk == 32) launch_one<128, 32, 32, 32, 32>(a, rows, ntiles, st);
-    else launch_one<128, 32, 32, 32, 64>(a, rows, ntiles, st);
+    a.num_pslots = rows;
+    a.num_ntiles = ntiles;
+    a.xcd_order = env_int("MCAMD_XCD_ORDER", 1);
+    const int stages = env_int("MCAMD_STAGES", t.bk == 32 ? 3 : 2);
+#define I_CASE(BN_, WM_, WN_, BK_, ST_)                              \
+    if (!done && t.bn == BN_ && t.bk == BK_ && stages == ST_) {       \
+        launch_one<128, BN_, WM_, WN_, BK_, ST_>(a, rows, ntiles, st); \
+        done = true;                                                  \
+    }
+    bool done = false;
+    if (t.bn == 128 && env_int("MCAMD_WAVES", 4) == 8) {   // 8-wave workgroups, one per CU
+        if (t.bk == 64 && stages == 3) { launch_one<128, 128, 32, 64, 64, 3>(a, rows, ntiles, st); done = true; }
+        else if (t.bk == 64 && stages == 2) { launch_one<128, 128, 32, 64, 64, 2>(a, rows, ntiles, st); done = true; }
+        else if (t.bk == 64 && stages == 4) { launch_one<128, 128, 32, 64, 64, 4>(a, rows, ntiles, st); done = true; }
+        else if (t.bk == 32 && stages == 4) { launch_one<128, 128, 32, 64, 32, 4>(a, rows, ntiles, st); done = true; }
+    }
+    I_CASE(128, 64, 64, 32, 2) I_CASE(128, 64, 64, 32, 3) I_CASE(128, 64, 64, 32, 4)
+    I_CASE(128, 64, 64, 64, 2) I_CASE(128, 64, 64, 64, 3)
+    I_CASE(64, 64, 32, 32, 2) I_CASE(64, 64, 32, 32, 3) I_CASE(64, 64, 32, 32, 4)
+    I_CASE(64, 64, 32, 64, 2) I_CASE(64, 64, 32, 64, 3)
+    I_CASE(32, 32, 32, 32, 2) I_CASE(32, 32, 32, 32, 3) I_CASE(32, 32, 32, 32, 4)
+    I_CASE(32, 32, 32, 64, 2) I_CASE(32, 32, 32, 64, 3)
+#undef I_CASE
+    if (!done) {
+        mcamd_set_error("igemm: no kernel instance for BN %d BK %d stages %d", t.bn, t.bk, stages);
+        return MCAMD_EINVAL;
+    }
     MCAMD_LAUNCH_CHECK("igemm");
     return MCAMD_OK;
 }

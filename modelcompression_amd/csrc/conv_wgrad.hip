@@ -70,7 +70,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     static_assert(NI == 1 || NI == 2 || NI == 4, "TMo in {32, 64, 128}");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // provably wave-uniform (readfirstlane): otherwise hipcc wraps every LDS-DMA in a waterfall loop
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave % NI, part = wave / NI;
 
     // XCD-aware order: work items are numbered split-major (all tiles of a split stream the same
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         char* sb = sa + A_SLOTS * 16;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            int wslot = it * NT + (tid & ~63);
+            int wslot = it * NT + wave * 64;
             if (wslot < A_SLOTS) {
                 const half_t* src;
                 if (pa[it].m < k1)
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            int wslot = it * NT + (tid & ~63);
+            int wslot = it * NT + wave * 64;
             if (wslot < B_SLOTS) {
                 const half_t* src;
                 if (pb[it].m < k1)
@@ -186,16 +188,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         const char* sb = sa + A_SLOTS * 16;
 #pragma unroll
         for (int s = 0; s < KP / 16; ++s) {
+            // all fragments of this k16 step first, then the MFMAs back to back
             const h8_t af = tr_frag<RBA>(sa, s, wi * 32, lane);
+            h8_t bf[NACC];
 #pragma unroll
             for (int idx = 0; idx < NACC; ++idx) {
-                const int q = part + WPI * idx;     // (tap, cin-block) task of this wave
-                if (q < NT2) {
-                    const int tapl = q / NJ, jn = q - tapl * NJ;
-                    const h8_t bf = tr_frag<RBB>(sb + tapl * (KP * RBB), s, jn * 32, lane);
-                    acc[idx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[idx], 0, 0, 0);
-                }
+                int q = part + WPI * idx;     // (tap, cin-block) task of this wave
+                if (q > NT2 - 1) q = NT2 - 1;  // surplus slot of an uneven split: valid address, result unused
+                const int tapl = q / NJ, jn = q - tapl * NJ;
+                bf[idx] = tr_frag<RBB>(sb + tapl * (KP * RBB), s, jn * 32, lane);
             }
+#pragma unroll
+            for (int idx = 0; idx < NACC; ++idx)
+                acc[idx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[idx], acc[idx], 0, 0, 0);
         }
     }
 

@@ -24,6 +24,9 @@ struct IgemmArgs {
     int stats_ld;
     float slope;
     int num_mtiles;
+    int num_pslots;  // persistent workgroups along M (= rows of the statistics slab)
+    int num_ntiles;
+    int xcd_order;
 };
 
 struct WgradArgs {
