@@ -77,7 +77,7 @@ typedef struct mcamd_conv_epilogue {
                                   per-channel sums (index 0) and sums of squares (index 1) over the pixels
                                   that persistent workgroup p processed (fixed order: deterministic) */
     int32_t stats_rows;        /* must equal mcamd_conv_stats_rows(geom) */
-    int32_t stats_ld;          /* >= round_up(cout, 128) */
+    int32_t stats_ld;          /* >= round_up(cout, 256) */
     const float* scale;        /* mode 2, may be NULL (=1) */
     const float* shift;        /* mode 2, may be NULL (=0) */
     float slope;               /* mode 2: negative-side slope (0.1 leaky, 1.0 linear) */
@@ -96,9 +96,9 @@ int64_t mcamd_packed_elems_dgrad(const mcamd_conv_geom* g);
 
 /* OIHW fp32 master (optionally * mask) -> fp16 kernel layouts.  Replaces the per-forward
  * `self.weight * mask_var` of layers.py:59 (done once per optimizer step here).
- *   fwd  : [Npad][t*cin + c]  = w[n][c][ty][tx],  t = ty*k + tx;  Npad = roundup(cout,128); pad rows zero
+ *   fwd  : [Npad][t*cin + c]  = w[n][c][ty][tx],  t = ty*k + tx;  Npad = roundup(cout,256); pad rows zero
  *          (stem: [Npad][ty*32 + tx*4 + c], other slots zero)
- *   dgrad: [Cpad][t*cout_p + n] = w[n][c][k-1-ty][k-1-tx]; cout_p = roundup(cout,32); Cpad = roundup(cin,128)
+ *   dgrad: [Cpad][t*cout_p + n] = w[n][c][k-1-ty][k-1-tx]; cout_p = roundup(cout,32); Cpad = roundup(cin,256)
  * Either destination may be NULL. */
 int mcamd_pack_weights(const mcamd_conv_geom* g, const float* w_oihw, const float* mask_oihw,
                        void* wp_fwd, void* wp_dgrad, void* stream);

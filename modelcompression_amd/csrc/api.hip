@@ -56,11 +56,11 @@ static void fill_taps(int ksize, int stem, int row_stride, int ld, int* taps) {
 
 extern "C" int64_t mcamd_packed_elems_fwd(const mcamd_conv_geom* g) {
     if (!g) return 0;
-    return (int64_t)round_up_int(g->cout, 128) * ntaps_of(g) * cin_tap_of(g);
+    return (int64_t)round_up_int(g->cout, 256) * ntaps_of(g) * cin_tap_of(g);
 }
 extern "C" int64_t mcamd_packed_elems_dgrad(const mcamd_conv_geom* g) {
     if (!g || g->stem) return 0;
-    return (int64_t)round_up_int(g->cin, 128) * g->ksize * g->ksize * cout_p_of(g);
+    return (int64_t)round_up_int(g->cin, 256) * g->ksize * g->ksize * cout_p_of(g);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -145,7 +145,7 @@ extern "C" int mcamd_pack_weights(const mcamd_conv_geom* g, const float* w_oihw,
 // ---------------------------------------------------------------------------------------
 // forward / dgrad
 // ---------------------------------------------------------------------------------------
-static int fill_epilogue(IgemmArgs& a, const mcamd_conv_epilogue* e, int n_out, long long M, int cin_tap,
+static int fill_epilogue(IgemmArgs& a, const mcamd_conv_epilogue* e, int n_out, long long M, int cin_tap, int ktot,
                          const char* what) {
     MCAMD_REQUIRE(e && e->y, "%s: null output", what);
     a.y = e->y;
@@ -165,11 +165,11 @@ static int fill_epilogue(IgemmArgs& a, const mcamd_conv_epilogue* e, int n_out, 
         MCAMD_REQUIRE(e->y_ld % 8 == 0 && e->y_choff % 8 == 0 && e->y_choff + n_out <= e->y_ld,
                       "%s: output slice [%d, %d) does not fit y_ld %d", what, e->y_choff, e->y_choff + n_out, e->y_ld);
         if (e->mode == MCAMD_EPI_RAW_F16 && e->stats) {
-            int rows = mcamd_igemm_rows(M, n_out, cin_tap);
+            int rows = mcamd_igemm_rows(M, n_out, cin_tap, ktot);
             MCAMD_REQUIRE(e->stats_rows == rows, "%s: stats_rows must be mcamd_conv_stats_rows() = %d (got %d)", what, rows,
                           e->stats_rows);
-            MCAMD_REQUIRE(e->stats_ld >= round_up_int(n_out, 128), "%s: stats_ld must be >= %d", what,
-                          round_up_int(n_out, 128));
+            MCAMD_REQUIRE(e->stats_ld >= round_up_int(n_out, 256), "%s: stats_ld must be >= %d", what,
+                          round_up_int(n_out, 256));
             a.stats = e->stats;
             a.stats_ld = e->stats_ld;
         }
@@ -186,13 +186,14 @@ static int fill_epilogue(IgemmArgs& a, const mcamd_conv_epilogue* e, int n_out, 
 
 extern "C" int32_t mcamd_conv_stats_rows(const mcamd_conv_geom* g) {
     if (!g) return 0;
-    return mcamd_igemm_rows((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g));
+    return mcamd_igemm_rows((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g), ntaps_of(g) * cin_tap_of(g));
 }
 
 extern "C" int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int32_t out[3]) {
     if (check_geom(g, "conv_tile_info")) return MCAMD_EINVAL;
     MCAMD_REQUIRE(out, "conv_tile_info: null output");
-    mcamd_igemm_tile(dgrad ? g->cin : g->cout, dgrad ? cout_p_of(g) : cin_tap_of(g), out);
+    mcamd_igemm_tile((long long)g->B * g->H * g->W, dgrad ? g->cin : g->cout, dgrad ? cout_p_of(g) : cin_tap_of(g),
+                     dgrad ? g->ksize * g->ksize * cout_p_of(g) : ntaps_of(g) * cin_tap_of(g), out);
     return MCAMD_OK;
 }
 
@@ -215,7 +216,7 @@ extern "C" int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const voi
     a.ntaps = ntaps_of(g);
     a.ktot = a.ntaps * a.cin_tap;
     fill_taps(g->ksize, g->stem, a.x_row_stride, g->x_ld, a.tap_off);
-    if (fill_epilogue(a, epi, g->cout, a.M, a.cin_tap, "conv_fwd")) return MCAMD_EINVAL;
+    if (fill_epilogue(a, epi, g->cout, a.M, a.cin_tap, a.ktot, "conv_fwd")) return MCAMD_EINVAL;
     return mcamd_igemm_launch(a, (hipStream_t)stream);
 }
 
@@ -243,7 +244,7 @@ extern "C" int mcamd_conv_dgrad(const mcamd_conv_geom* g, const void* dy, int32_
     a.ktot = a.ntaps * a.cin_tap;
     fill_taps(g->ksize, 0, a.x_row_stride, dy_ld, a.tap_off);
     MCAMD_REQUIRE(epi && epi->mode != MCAMD_EPI_PAD_F16 && !epi->stats, "conv_dgrad: epilogue must be mode 0 (no stats) or 1");
-    if (fill_epilogue(a, epi, g->cin, a.M, a.cin_tap, "conv_dgrad")) return MCAMD_EINVAL;
+    if (fill_epilogue(a, epi, g->cin, a.M, a.cin_tap, a.ktot, "conv_dgrad")) return MCAMD_EINVAL;
     return mcamd_igemm_launch(a, (hipStream_t)stream);
 }
 

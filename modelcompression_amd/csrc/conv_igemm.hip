@@ -164,7 +164,8 @@ void igemm_kernel(IgemmArgs a) {
             // Fragment reads are software-pipelined: the ds_reads of k16 sub-step s+1 are issued before the
             // MFMAs of sub-step s (two fragment sets), so LDS latency hides under the matrix pipe.
             constexpr int KS = BK / 16;
-            h8_t af[2][TM], bf[2][TN];
+            constexpr int NSET = 2;
+            h8_t af[NSET][TM], bf[NSET][TN];
             auto load_frags = [&](int s, int set) {
                 const int chunk = 2 * s + (lane >> 5);
 #pragma unroll
@@ -178,17 +179,22 @@ void igemm_kernel(IgemmArgs a) {
                     bf[set][j] = *(const h8_t*)(sb + (row * CPR + (chunk ^ swz<CPR>(row))) * 16);
                 }
             };
-            load_frags(0, 0);
+            if (NSET == 2) load_frags(0, 0);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                if (s + 1 < KS) load_frags(s + 1, (s + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this sub-step's MFMAs
+                if (NSET == 2) {
+                    if (s + 1 < KS) load_frags(s + 1, (s + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this sub-step's MFMAs
+                } else {
+                    load_frags(s, 0);
+                }
+                constexpr int M1 = NSET - 1;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s & 1][i], bf[s & 1][j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s & M1][i], bf[s & M1][j], acc[i][j], 0, 0, 0);
+                if (NSET == 2) __builtin_amdgcn_sched_barrier(0);
             }
         }
 
@@ -309,34 +315,58 @@ static int env_int(const char* name, int dflt) {
     return s && *s ? atoi(s) : dflt;
 }
 
-static TileCfg pick_tile(int n, int cin_tap) {
-    // N tile: the candidate with the least padding, larger on ties (125 -> 128, 192 -> 64, 32 -> 32).
+// Workgroup tile for an implicit GEMM of M pixels x n channels.  The L2->LDS operand stream bounds
+// the kernel (bytes per flop = (1/BM + 1/BN) / 1), so bigger tiles are faster per tile, but the
+// machine has 256 CUs and the late layers have few tiles: pick the candidate with the best
+// (rate of the tile shape) x (fill of the last round of workgroups).
+static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot) {
     TileCfg t;
-    t.bm = 128;
     int best = 128, waste = round_up_int(n, 128);
     for (int bn = 64; bn >= 32; bn /= 2)
         if (round_up_int(n, bn) < waste) {
             waste = round_up_int(n, bn);
             best = bn;
         }
+    t.bm = 128;
     t.bn = best;
     int want_bk = env_int("MCAMD_BK", 64);
     t.bk = (want_bk == 64 && cin_tap % 64 == 0) ? 64 : 32;
+    if (t.bk == 64 && best == 128 && env_int("MCAMD_BIG_TILES", 0)) {
+        // measured on MI355X (profiles/r01_*): TFLOP/s of a full machine ~ rinf * K / (K + k0); k0 is the
+        // epilogue + prologue cost of the tile shape expressed in K elements
+        struct Cand { int bm, bn; double rinf, k0; int per_cu; };
+        const Cand cands[3] = {{128, 128, 800.0, 250.0, 2}, {256, 128, 1000.0, 500.0, 1}, {256, 256, 1350.0, 2900.0, 1}};
+        double best_score = 0;
+        const int fbm = env_int("MCAMD_FORCE_BM", 0), fbn = env_int("MCAMD_FORCE_BN", 0);
+        for (int c = 0; c < 3; ++c) {
+            if (cands[c].bn == 256 && n % 256 != 0) continue;   // packed weights are padded to 256 rows only
+            long long tiles = ((M + cands[c].bm - 1) / cands[c].bm) * ((n + cands[c].bn - 1) / cands[c].bn);
+            long long slots = 256LL * cands[c].per_cu;
+            double fill = (double)tiles / (double)(((tiles + slots - 1) / slots) * slots);
+            double score = cands[c].rinf * ktot / (ktot + cands[c].k0) * fill;
+            if (fbm == cands[c].bm && (!fbn || fbn == cands[c].bn)) score += 1e9;   // forced (tests / sweeps)
+            if (score > best_score) {
+                best_score = score;
+                t.bm = cands[c].bm;
+                t.bn = cands[c].bn;
+            }
+        }
+    }
     return t;
 }
 
-void mcamd_igemm_tile(int n, int cin_tap, int out[3]) {
-    TileCfg t = pick_tile(n, cin_tap);
+void mcamd_igemm_tile(long long M, int n, int cin_tap, int ktot, int out[3]) {
+    TileCfg t = pick_tile(M, n, cin_tap, ktot);
     out[0] = t.bm, out[1] = t.bn, out[2] = t.bk;
 }
 
-int mcamd_igemm_mtiles(long long M) { return (int)((M + 127) / 128); }
+static int igemm_mtiles(long long M, int bm) { return (int)((M + bm - 1) / bm); }
 
 // Number of persistent workgroups along M (== rows of the BN-statistics slab).
-int mcamd_igemm_rows(long long M, int n, int cin_tap) {
-    TileCfg t = pick_tile(n, cin_tap);
+int mcamd_igemm_rows(long long M, int n, int cin_tap, int ktot) {
+    TileCfg t = pick_tile(M, n, cin_tap, ktot);
     int ntiles = (n + t.bn - 1) / t.bn;
-    int mtiles = mcamd_igemm_mtiles(M);
+    int mtiles = igemm_mtiles(M, t.bm);
     int target = env_int("MCAMD_IGEMM_WGS", 2048);
     int p = target / ntiles;
     if (p < 1) p = 1;
@@ -362,25 +392,27 @@ static void launch_one(const IgemmArgs& a, int rows, int ntiles, hipStream_t st)
 
 // a.* geometry fields must be filled by the caller; picks the tile and launches.
 int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st) {
-    TileCfg t = pick_tile(a.N, a.cin_tap);
+    TileCfg t = pick_tile(a.M, a.N, a.cin_tap, a.ktot);
     if (a.cin_tap % t.bk != 0 || a.ktot % t.bk != 0) {
         mcamd_set_error("igemm: K per tap (%d) must be a multiple of %d", a.cin_tap, t.bk);
         return MCAMD_EINVAL;
     }
     int ntiles = (a.N + t.bn - 1) / t.bn;
-    a.num_mtiles = mcamd_igemm_mtiles(a.M);
-    int rows = mcamd_igemm_rows(a.M, a.N, a.cin_tap);
+    a.num_mtiles = igemm_mtiles(a.M, t.bm);
+    int rows = mcamd_igemm_rows(a.M, a.N, a.cin_tap, a.ktot);
     a.num_pslots = rows;
     a.num_ntiles = ntiles;
     a.xcd_order = env_int("MCAMD_XCD_ORDER", 1);
     const int stages = env_int("MCAMD_STAGES", t.bk == 32 ? 3 : 2);
 #define I_CASE(BN_, WM_, WN_, BK_, ST_)                              \
-    if (!done && t.bn == BN_ && t.bk == BK_ && stages == ST_) {       \
+    if (!done && t.bm == 128 && t.bn == BN_ && t.bk == BK_ && stages == ST_) { \
         launch_one<128, BN_, WM_, WN_, BK_, ST_>(a, rows, ntiles, st); \
         done = true;                                                  \
     }
     bool done = false;
-    if (t.bn == 128 && env_int("MCAMD_WAVES", 4) == 8) {   // 8-wave workgroups, one per CU
+    if (t.bm == 256 && t.bn == 256) { launch_one<256, 256, 128, 64, 64, 2>(a, rows, ntiles, st); done = true; }
+    if (t.bm == 256 && t.bn == 128) { launch_one<256, 128, 64, 64, 64, 2>(a, rows, ntiles, st); done = true; }
+    if (!done && t.bn == 128 && env_int("MCAMD_WAVES", 4) == 8) {   // 8-wave workgroups, one per CU
         if (t.bk == 64 && stages == 3) { launch_one<128, 128, 32, 64, 64, 3>(a, rows, ntiles, st); done = true; }
         else if (t.bk == 64 && stages == 2) { launch_one<128, 128, 32, 64, 64, 2>(a, rows, ntiles, st); done = true; }
         else if (t.bk == 64 && stages == 4) { launch_one<128, 128, 32, 64, 64, 4>(a, rows, ntiles, st); done = true; }

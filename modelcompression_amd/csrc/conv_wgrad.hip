@@ -349,6 +349,7 @@ static int pick_taps(int tmo, int tnc, int ntaps) {
 }
 
 static int pick_kp(int tmo, int tnc, int taps) {
+    if (tmo == 128 && tnc == 128 && taps == 1) return env_int_w("MCAMD_WGRAD_KP_BIG", 32);
     const int budget = env_int_w("MCAMD_WGRAD_STAGE_KB", 24) * 1024;
     for (int kp = 128; kp > 32; kp /= 2)
         if (kp * 2 * (tmo + taps * tnc) <= budget) return kp;

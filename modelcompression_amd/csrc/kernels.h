@@ -52,9 +52,8 @@ struct WgradPlan {
     size_t bytes;
 };
 
-void mcamd_igemm_tile(int n, int cin_tap, int out[3]);
-int mcamd_igemm_mtiles(long long M);
-int mcamd_igemm_rows(long long M, int n, int cin_tap);
+void mcamd_igemm_tile(long long M, int n, int cin_tap, int ktot, int out[3]);
+int mcamd_igemm_rows(long long M, int n, int cin_tap, int ktot);
 int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st);
 
 WgradPlan mcamd_wgrad_plan(long long M, int cout, int cin_tap, int ntaps);

@@ -229,7 +229,7 @@ class Engine:
                 lay.gin = torch.empty(lay.M * lay.tin.ld, dtype=ops.HALF, device=dev)
             if not lay.is_last:
                 lay.y = torch.empty(lay.M * lay.cout, dtype=ops.HALF, device=dev)
-                lay.stats = torch.empty(ops.stats_rows(g), 2, ops.round_up(lay.cout, 128), **f32)
+                lay.stats = torch.empty(ops.stats_rows(g), 2, ops.round_up(lay.cout, 256), **f32)
                 lay.scale, lay.shift, lay.mean, lay.invstd = (torch.empty(lay.cout, **f32) for _ in range(4))
                 lay.out_t = place.get(lay.out_id)
                 lay.out2_t = place.get(lay.out2_id) if lay.out2_id is not None else None

@@ -59,7 +59,7 @@ def test_conv_fwd_raw_and_stats(dev, case, bk, monkeypatch):
     y_ld = ops.round_up(cout, 8)
     y = torch.zeros(B * H * W * y_ld, dtype=torch.float16, device=dev)
     rows = ops.stats_rows(g)
-    stats = torch.full((rows, 2, ops.round_up(cout, 128)), float("nan"), dtype=torch.float32, device=dev)
+    stats = torch.full((rows, 2, ops.round_up(cout, 256)), float("nan"), dtype=torch.float32, device=dev)
     if cout % 8 == 0:
         ops.conv_fwd_raw(g, xb, wp, y, y_ld, 0, stats)
         got = raw_to_nchw(y, B, H, W, y_ld, cout)
@@ -103,7 +103,7 @@ def test_conv_fwd_stem(dev):
     assert wd is None
     y = torch.zeros(B * H * W * cout, dtype=torch.float16, device=dev)
     rows = ops.stats_rows(g)
-    stats = torch.zeros(rows, 2, 128, device=dev)
+    stats = torch.zeros(rows, 2, 256, device=dev)
     ops.conv_fwd_raw(g, xb, wp, y, cout, 0, stats)
     got = raw_to_nchw(y, B, H, W, cout, cout)
     ref = F.conv2d(q16(x), q16(w), None, 1, 1)

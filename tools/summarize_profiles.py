@@ -1,0 +1,56 @@
+"""Summarise gpurun_out/prof_final into profiles/ (tracked): kernel stats, per-kernel PMC table,
+and the HBM traffic of the dominant kernel (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE)."""
+import collections, csv, glob, json, os, shutil, sys
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_final"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+os.makedirs("profiles", exist_ok=True)
+def one(pat):
+    g = glob.glob(os.path.join(src, pat))
+    return g[0] if g else None
+st = one("stats/*/*kernel_stats.csv")
+shutil.copy(st, "profiles/%s_kernel_stats.csv" % tag)
+shutil.copy(os.path.join(src, "layer_table.txt"), "profiles/%s_layer_table.txt" % tag)
+def pmc(sub):
+    rows = list(csv.DictReader(open(one(sub + "/*/*counter_collection.csv"))))
+    disp = collections.defaultdict(dict)
+    for r in rows:
+        d = disp[r["Dispatch_Id"]]
+        d["k"] = r["Kernel_Name"]
+        d[r["Counter_Name"]] = float(r["Counter_Value"])
+        d["us"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    for d in disp.values():
+        a = agg[d["k"]]
+        a["launches"] += 1
+        for k, v in d.items():
+            if k != "k":
+                a[k] += v
+    return agg
+fetch, write, sq, tcc = pmc("fetch"), pmc("write"), pmc("sq"), pmc("tcc")
+out = {}
+for k in fetch:
+    n = fetch[k]["launches"]
+    e = {"launches": int(n), "avg_us": fetch[k]["us"] / n,
+         "fetch_bytes_per_launch": fetch[k]["FETCH_SIZE"] * 1024 * 2 / n,      # KB units; x2: gfx950 FETCH_SIZE correction
+         "write_bytes_per_launch": write.get(k, {}).get("WRITE_SIZE", 0) * 1024 / max(write.get(k, {}).get("launches", 1), 1)}
+    e["hbm_bytes_per_launch"] = e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"]
+    if k in tcc and tcc[k]["TCC_HIT_sum"] + tcc[k]["TCC_MISS_sum"] > 0:
+        e["l2_hit_rate"] = tcc[k]["TCC_HIT_sum"] / (tcc[k]["TCC_HIT_sum"] + tcc[k]["TCC_MISS_sum"])
+    if k in sq and sq[k]["SQ_WAVE_CYCLES"] > 0:
+        wc = sq[k]["SQ_WAVE_CYCLES"]
+        e["wait_any_frac"] = sq[k]["SQ_WAIT_ANY"] / wc
+        e["active_inst_frac"] = sq[k]["SQ_ACTIVE_INST_ANY"] / wc
+        e["mfma_busy_cycles_per_launch"] = sq[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / sq[k]["launches"]
+        e["lds_bank_conflict"] = sq[k]["SQ_LDS_BANK_CONFLICT"]
+    out[k] = e
+top = sorted(out.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches"])[:14]
+json.dump(dict(top), open("profiles/%s_pmc_per_kernel.json" % tag, "w"), indent=1)
+dom = [k for k in out if k.startswith("void igemm_kernel<128, 128, 64, 64")]
+if dom:
+    k = max(dom, key=lambda k: out[k]["launches"])
+    json.dump({"kernel": k, "hbm_bytes_per_launch": out[k]["hbm_bytes_per_launch"], "launches_profiled": out[k]["launches"],
+               "fetch_bytes_per_launch": out[k]["fetch_bytes_per_launch"], "write_bytes_per_launch": out[k]["write_bytes_per_launch"],
+               "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"},
+              open("profiles/dominant_kernel_traffic.json", "w"), indent=1)
+    print(k, out[k])
+shutil.copy(os.path.join(src, "bench.json"), "profiles/%s_bench.json" % tag)
