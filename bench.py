@@ -67,7 +67,11 @@ def main():
     from modelcompression_amd import nets, dp, YOLOV2_VOC_CFG, ops
     from modelcompression_amd.synthetic import init_synthetic, synthetic_batch
 
-    rank, world = dp.init_from_env()
+    # MCAMD_DP_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N>1 path on a 1-GPU box)
+    backend = os.environ.get("MCAMD_DP_BACKEND") or None
+    ndev = max(torch.cuda.device_count(), 1)
+    os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % ndev)
+    rank, world = dp.init_from_env(backend)
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     torch.cuda.set_device(local)
@@ -90,7 +94,7 @@ def main():
 
     def fence():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local]) if dist.get_backend() == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):

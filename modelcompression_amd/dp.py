@@ -14,7 +14,9 @@ import torch.distributed as dist
 
 
 def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun)."""
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).
+    The rank's GPU is selected BEFORE the process group is created and handed to it as
+    `device_id`, so RCCL communicators and barriers are bound to the right device."""
     import os
     if dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -24,7 +26,13 @@ def init_from_env(backend=None):
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group(backend=backend)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (see the environment notes)
+    kwargs = {}
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+        torch.cuda.set_device(local)
+        kwargs["device_id"] = torch.device("cuda", local)
+    dist.init_process_group(backend=backend, **kwargs)
     return dist.get_rank(), dist.get_world_size()
 
 

@@ -400,8 +400,43 @@ def gen_sgd():
     print("wrote sgd_step.npz")
 
 
+def gen_region_loss():
+    """RegionLoss / build_targets (nets.py:282-635) on the CPU.  The reference hard-codes
+    torch.cuda.*Tensor and .cuda(); shims redirect them to the CPU for
+    the duration of this call only."""
+    saved = (torch.cuda.FloatTensor, torch.cuda.LongTensor, torch.Tensor.cuda)
+    torch.cuda.FloatTensor, torch.cuda.LongTensor = torch.FloatTensor, torch.LongTensor
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        arrays = {}
+        g = torch.Generator().manual_seed(11)
+        for case, (B, boxes) in enumerate([(2, [[(3, .5, .5, .3, .4), (7, .2, .7, .1, .2)], [(11, .8, .1, .5, .15)]]),
+                                           (3, [[(0, .31, .62, .8, .7)], [], [(19, .05, .95, .08, .06), (5, .5, .5, .2, .9),
+                                                                               (5, .52, .5, .21, .88)]])]):
+            out = (torch.randn(B, 125, 13, 13, generator=g) * 0.7).requires_grad_(True)
+            target = torch.zeros(B, 250)
+            for b, bl in enumerate(boxes):
+                for t, bx in enumerate(bl):
+                    target[b, t * 5:(t + 1) * 5] = torch.tensor(bx)
+            loss_mod = ref_nets.RegionLoss()
+            loss_mod.object_scale, loss_mod.noobject_scale, loss_mod.class_scale, loss_mod.coord_scale = 5.0, 1.0, 1.0, 1.0
+            loss = quiet(loss_mod, out, target)
+            loss.backward()
+            arrays["c%d_out" % case], arrays["c%d_target" % case] = out.detach().numpy(), target.numpy()
+            arrays["c%d_loss" % case] = np.float32(loss.item())
+            arrays["c%d_grad" % case] = out.grad.numpy()
+            print("  region loss case %d: %.6f" % (case, loss.item()))
+        np.savez_compressed(os.path.join(HERE, "region_loss.npz"), **arrays)
+        print("wrote region_loss.npz")
+    finally:
+        torch.cuda.FloatTensor, torch.cuda.LongTensor, torch.Tensor.cuda = saved
+
+
 def main():
     torch.manual_seed(0)
+    if "--only-region" in sys.argv:
+        gen_region_loss()
+        return
     torch.set_num_threads(8)
     gen_cfg()
     gen_structure()
@@ -413,6 +448,7 @@ def main():
     if "--skip-full" not in sys.argv:
         prune["yolov2_voc"] = gen_prune("yolov2_voc", YOLO_CFG_REF, [30.0, 80.0], [40.0, 60.0], True)
         prune["yolo_io"] = gen_yolo_logits()
+    gen_region_loss()
     prune["versions"] = {"numpy": np.__version__, "torch": torch.__version__}
     dump_json("prune_golden.json", prune)
 

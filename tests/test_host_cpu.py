@@ -201,3 +201,19 @@ def test_data_parallel_reducer_gloo_world2(tmp_path):
     s.close()
     mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+def test_region_loss_matches_reference_golden():
+    """RegionLoss + build_targets (nets.py:282-635) against values recorded from the reference
+    (CPU shims, tests/golden/gen_golden.py::gen_region_loss): loss and d(loss)/d(output)."""
+    from modelcompression_amd.region_loss import RegionLoss
+    gold = np.load(os.path.join(G, "region_loss.npz"))
+    for case in (0, 1):
+        out = torch.from_numpy(gold["c%d_out" % case]).clone().requires_grad_(True)
+        target = torch.from_numpy(gold["c%d_target" % case])
+        loss = RegionLoss()
+        loss.object_scale, loss.noobject_scale, loss.class_scale, loss.coord_scale = 5.0, 1.0, 1.0, 1.0
+        val = loss(out, target)
+        val.backward()
+        assert abs(float(val) - float(gold["c%d_loss" % case])) <= 1e-4 * abs(float(gold["c%d_loss" % case])), case
+        assert torch.allclose(out.grad, torch.from_numpy(gold["c%d_grad" % case]), rtol=1e-4, atol=1e-6), case
