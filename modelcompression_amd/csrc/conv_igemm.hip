@@ -331,7 +331,8 @@ static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot) {
     t.bn = best;
     int want_bk = env_int("MCAMD_BK", 64);
     t.bk = (want_bk == 64 && cin_tap % 64 == 0) ? 64 : 32;
-    if (t.bk == 64 && best == 128 && env_int("MCAMD_BIG_TILES", 0)) {
+    if ((t.bk == 64 || env_int("MCAMD_BIG_BK32", 0)) && best == 128 && env_int("MCAMD_BIG_TILES", 0)) {
+        if (env_int("MCAMD_BIG_BK32", 0) && cin_tap % 32 == 0) t.bk = 32;
         // measured on MI355X (profiles/r01_*): TFLOP/s of a full machine ~ rinf * K / (K + k0); k0 is the
         // epilogue + prologue cost of the tile shape expressed in K elements
         struct Cand { int bm, bn; double rinf, k0; int per_cu; };
@@ -410,8 +411,10 @@ int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st) {
         done = true;                                                  \
     }
     bool done = false;
-    if (t.bm == 256 && t.bn == 256) { launch_one<256, 256, 128, 64, 64, 2>(a, rows, ntiles, st); done = true; }
-    if (t.bm == 256 && t.bn == 128) { launch_one<256, 128, 64, 64, 64, 2>(a, rows, ntiles, st); done = true; }
+    if (t.bm == 256 && t.bn == 256 && t.bk == 32) { launch_one<256, 256, 128, 64, 32, 4>(a, rows, ntiles, st); done = true; }
+    if (!done && t.bm == 256 && t.bn == 128 && t.bk == 32) { launch_one<256, 128, 64, 64, 32, 4>(a, rows, ntiles, st); done = true; }
+    if (!done && t.bm == 256 && t.bn == 256) { launch_one<256, 256, 128, 64, 64, 2>(a, rows, ntiles, st); done = true; }
+    if (!done && t.bm == 256 && t.bn == 128) { launch_one<256, 128, 64, 64, 64, 2>(a, rows, ntiles, st); done = true; }
     if (!done && t.bn == 128 && env_int("MCAMD_WAVES", 4) == 8) {   // 8-wave workgroups, one per CU
         if (t.bk == 64 && stages == 3) { launch_one<128, 128, 32, 64, 64, 3>(a, rows, ntiles, st); done = true; }
         else if (t.bk == 64 && stages == 2) { launch_one<128, 128, 32, 64, 64, 2>(a, rows, ntiles, st); done = true; }

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     constexpr int NT = 256;
     constexpr int NI = TMo / 32, WPI = 4 / NI, NJ = TNc / 32;
     constexpr int NT2 = TAPS * NJ, NACC = (NT2 + WPI - 1) / WPI;
+    constexpr bool SQ = (TAPS == 1 && NI == 4 && NJ == 4);   // then NACC == 4 as well
     constexpr int RBA = TMo * 2, RBB = TNc * 2;
     constexpr int A_CH = TMo / 8, B_CH = TNc / 8;
     constexpr int A_SLOTS = KP * A_CH, B_SLOTS = TAPS * KP * B_CH;
@@ -188,31 +189,49 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         const char* sb = sa + A_SLOTS * 16;
 #pragma unroll
         for (int s = 0; s < KP / 16; ++s) {
-            // all fragments of this k16 step first, then the MFMAs back to back
-            const h8_t af = tr_frag<RBA>(sa, s, wi * 32, lane);
-            h8_t bf[NACC];
+            if constexpr (SQ) {
+                // 128x128, one tap: 2x2 waves of 64x64 (2 A + 2 B fragments feed 4 MFMAs)
+                h8_t af2[2], bf2[2];
 #pragma unroll
-            for (int idx = 0; idx < NACC; ++idx) {
-                int q = part + WPI * idx;     // (tap, cin-block) task of this wave
-                if (q > NT2 - 1) q = NT2 - 1;  // surplus slot of an uneven split: valid address, result unused
-                const int tapl = q / NJ, jn = q - tapl * NJ;
-                bf[idx] = tr_frag<RBB>(sb + tapl * (KP * RBB), s, jn * 32, lane);
+                for (int i = 0; i < 2; ++i) af2[i] = tr_frag<RBA>(sa, s, (wave >> 1) * 64 + i * 32, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf2[j] = tr_frag<RBB>(sb, s, (wave & 1) * 64 + j * 32, lane);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af2[i], bf2[j], acc[i * 2 + j], 0, 0, 0);
+            } else {
+                // all fragments of this k16 step first, then the MFMAs back to back
+                const h8_t af = tr_frag<RBA>(sa, s, wi * 32, lane);
+                h8_t bf[NACC];
+#pragma unroll
+                for (int idx = 0; idx < NACC; ++idx) {
+                    int q = part + WPI * idx;     // (tap, cin-block) task of this wave
+                    if (q > NT2 - 1) q = NT2 - 1;  // surplus slot of an uneven split: valid address, result unused
+                    const int tapl = q / NJ, jn = q - tapl * NJ;
+                    bf[idx] = tr_frag<RBB>(sb + tapl * (KP * RBB), s, jn * 32, lane);
+                }
+#pragma unroll
+                for (int idx = 0; idx < NACC; ++idx)
+                    acc[idx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[idx], acc[idx], 0, 0, 0);
             }
-#pragma unroll
-            for (int idx = 0; idx < NACC; ++idx)
-                acc[idx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[idx], acc[idx], 0, 0, 0);
         }
     }
 
     float* out = a.slab + (long long)split * a.rows_pad * a.ktot;
 #pragma unroll
     for (int idx = 0; idx < NACC; ++idx) {
-        const int q = part + WPI * idx;
+        int q = part + WPI * idx, rowblk = wi * 32;
+        if (SQ) {
+            rowblk = (wave >> 1) * 64 + (idx >> 1) * 32;
+            q = (wave & 1) * 2 + (idx & 1);          // cin block 0..3 (one tap)
+        }
         if (q < NT2) {
             const int tapl = q / NJ, jn = q - tapl * NJ;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int n = ot * TMo + wi * 32 + mfma32_row(r, lane);
+                int n = ot * TMo + rowblk + mfma32_row(r, lane);
                 int k = (t0 + tapl) * a.cin_tap + ct * TNc + jn * 32 + (lane & 31);
                 out[(long long)n * a.ktot + k] = acc[idx][r];
             }

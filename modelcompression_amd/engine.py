@@ -326,7 +326,8 @@ class Engine:
     def backward(self, grad_out):
         """grad wrt the returned logits -> one flat fp32 gradient buffer; returns per-parameter views."""
         S = self.grad_scale
-        flat = torch.zeros(self.total_params, dtype=torch.float32, device=self.device)
+        # every element is written below (wgrad finish / dgamma / dbeta / dbias): no memset needed
+        flat = torch.empty(self.total_params, dtype=torch.float32, device=self.device)
         views = [flat[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.params)]
         gmap = {id(p): v for p, v in zip(self.params, views)}
         for lay in reversed(self.layers):

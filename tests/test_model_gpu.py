@@ -125,7 +125,7 @@ def test_mini_masked_training_steps(dev):
     assert prune_rate(m, verbose=False) > 50.0
 
 
-def _teacher_forced(dev, cfg, B, seed, masked):
+def _teacher_forced(dev, cfg, B, seed, masked, hw=None):
     """Every kernel of a training step, at the network's real shapes, against fp32 torch-CPU math
     fed with the ENGINE'S OWN inputs for that kernel (so errors cannot compound)."""
     import torch.nn.functional as F
@@ -133,7 +133,7 @@ def _teacher_forced(dev, cfg, B, seed, masked):
     from util import raw_to_nchw, padded_to_nchw
     blocks = O.parse_cfg(cfg)
     state = O.init_state(blocks, seed=seed)
-    H, W = int(blocks[0]["height"]), int(blocks[0]["width"])
+    H, W = hw if hw else (int(blocks[0]["height"]), int(blocks[0]["width"]))
     g = torch.Generator().manual_seed(seed + 100)
     x = torch.rand(B, 3, H, W, generator=g)
     m = nets.Darknet(cfg)
@@ -209,6 +209,11 @@ def _teacher_forced(dev, cfg, B, seed, masked):
 
 def test_layerwise_teacher_forced_mini(dev):
     _teacher_forced(dev, MINI, 2, 3, masked=True)
+
+
+def test_layerwise_teacher_forced_nonsquare_odd_batch(dev):
+    """The engine follows the input's shape, not the cfg's: non-square image, batch 3, ragged tiles."""
+    _teacher_forced(dev, MINI, 3, 9, masked=False, hw=(96, 160))
 
 
 def test_layerwise_teacher_forced_yolov2(dev):
