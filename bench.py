@@ -121,10 +121,9 @@ def main():
         a = per.setdefault(key, [0.0, 0, lay])
         a[0] += ms
         a[1] += 1
-    dom_ms = dom_flop = 0.0
-    dom_n = 0
     tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
     rows = []
+    by_tile = {}     # igemm instance (BM, BN, BK) -> [ms, flop, launches]
     for (tag, li), (ms, n, lay) in sorted(per.items(), key=lambda kv: (kv[0][1], kv[0][0])):
         fl = eng.conv_flops(lay)
         avg = ms / n
@@ -133,10 +132,14 @@ def main():
         tot[tag][1] += fl
         rows.append("%-6s conv%-2d %4dx%-4d cin %4d cout %4d k%d  %8.3f ms  %8.1f TFLOP/s  tile %s" % (
             tag, li + 1, lay.H, lay.W, lay.cin, lay.cout, lay.k, avg, fl / avg / 1e9, tile))
-        if tile is not None and tile[0] == 128 and tile[1] == 128:
-            dom_ms += ms
-            dom_flop += fl * n
-            dom_n += n
+        if tile is not None:
+            b = by_tile.setdefault(tile, [0.0, 0.0, 0])
+            b[0] += ms
+            b[1] += fl * n
+            b[2] += n
+    # the dominant kernel = the igemm instance with the largest total time in the timed region
+    dom_tile = max(by_tile, key=lambda t: by_tile[t][0])
+    dom_ms, dom_flop, dom_n = by_tile[dom_tile]
     achieved = dom_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process; they are
     # collected by tools/collect_profiles.sh on the same command (FETCH_SIZE and WRITE_SIZE in separate
@@ -145,7 +148,9 @@ def main():
     tfile = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
     if os.path.exists(tfile):
         try:
-            traffic = round(json.load(open(tfile))["hbm_bytes_per_launch"])
+            tj = json.load(open(tfile))
+            if tj["kernel"].startswith("void igemm_kernel<%d, %d," % dom_tile[:2]):
+                traffic = round(tj["hbm_bytes_per_launch"])
         except Exception:
             traffic = None
     step_ms = dt / args.steps * 1e3
@@ -170,7 +175,7 @@ def main():
         "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
                      "algorithmic_gflop_per_launch": round(dom_flop / max(dom_n, 1) / 1e9, 2),
-                     "kernel": "igemm_kernel<128,128,64,64,*> (conv fwd + dgrad launches)",
+                     "kernel": "igemm_kernel<%d,%d,..,%d,2,0> (conv fwd + dgrad launches of that instance)" % dom_tile,
                      "launches_per_step": dom_n // max(args.steps, 1),
                      "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4)},
     }

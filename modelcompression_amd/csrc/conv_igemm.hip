@@ -36,7 +36,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int NSTAGE>
+template <int BM, int BN, int WM, int WN, int BK, int NSTAGE, int EPI>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64,
                               ((BM / WM) * (BN / WN) >= 8 ? 2 : (BN >= 128 ? (NSTAGE * BK <= 96 ? 3 : 2) : (BN >= 64 ? 3 : 4))))
 void igemm_kernel(IgemmArgs a) {
@@ -164,7 +164,7 @@ void igemm_kernel(IgemmArgs a) {
             // Fragment reads are software-pipelined: the ds_reads of k16 sub-step s+1 are issued before the
             // MFMAs of sub-step s (two fragment sets), so LDS latency hides under the matrix pipe.
             constexpr int KS = BK / 16;
-            constexpr int NSET = 2;
+            constexpr int NSET = (TM * TN <= 4) ? 2 : 1;   // bigger wave tiles have no registers to spare
             h8_t af[NSET][TM], bf[NSET][TN];
             auto load_frags = [&](int s, int set) {
                 const int chunk = 2 * s + (lane >> 5);
@@ -199,7 +199,8 @@ void igemm_kernel(IgemmArgs a) {
         }
 
         // ------------------------------- epilogue -------------------------------
-        if (a.mode == MCAMD_EPI_NCHW_F32) {
+        if constexpr (EPI == MCAMD_EPI_NCHW_F32) {   // fp32 NCHW scatter (logits / per-layer API): its own instance, so its
+                                // address arithmetic does not inflate the registers of the fp16 path
             float* y = (float*)a.y;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -223,11 +224,12 @@ void igemm_kernel(IgemmArgs a) {
         } else {
             __syncthreads();  // every wave is done with the stage buffers
             half_t* ct = (half_t*)smem;  // [BM][BN] fp16 output tile
+            const int mlim = a.M - mt * BM;  // rows of this tile that are real pixels
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = wn * WN + j * 32 + (lane & 31);
                 float sc = 1.f, sh = 0.f;
-                if (a.mode == MCAMD_EPI_PAD_F16) {
+                if constexpr (EPI == MCAMD_EPI_PAD_F16) {
                     int n = nt * BN + col;
                     if (n < a.N) {
                         if (a.scale) sc = a.scale[n];
@@ -240,14 +242,14 @@ void igemm_kernel(IgemmArgs a) {
                     for (int r = 0; r < 16; ++r) {
                         const int row = wm * WM + i * 32 + mfma32_row(r, lane);
                         float v = acc[i][j][r];
-                        if (a.mode == MCAMD_EPI_PAD_F16) {
+                        if constexpr (EPI == MCAMD_EPI_PAD_F16) {
                             v = v * sc + sh;
                             v = v > 0.f ? v : v * a.slope;
                         }
                         half_t hv = (half_t)fminf(fmaxf(v, -65504.f), 65504.f);  // saturate, never inf
                         ct[row * BN + col] = hv;
-                        if (a.stats) {
-                            float fv = (mt * BM + row < a.M) ? (float)hv : 0.f;
+                        if (EPI == MCAMD_EPI_RAW_F16 && a.stats) {
+                            float fv = (row < mlim) ? (float)hv : 0.f;
                             s1[j] += fv;
                             s2[j] += fv * fv;
                         }
@@ -262,7 +264,7 @@ void igemm_kernel(IgemmArgs a) {
                 int n0 = nt * BN + ch * 8;
                 if (m < a.M && n0 < a.N) {
                     long long off;
-                    if (a.mode == MCAMD_EPI_PAD_F16) {
+                    if constexpr (EPI == MCAMD_EPI_PAD_F16) {
                         int b = m / a.HW;
                         int rem = m - b * a.HW;
                         int h = rem / a.W;
@@ -277,7 +279,7 @@ void igemm_kernel(IgemmArgs a) {
         }
     }
 
-    if (a.stats) {
+    if (EPI == MCAMD_EPI_RAW_F16 && a.stats) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             s1[j] += __shfl_xor(s1[j], 32);
@@ -353,6 +355,15 @@ static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot) {
             }
         }
     }
+    // Tile quantisation: 2 workgroups per CU = 512 slots.  A 192-row tile (wave tile 96x64) often turns
+    // a nearly empty last round into none (13x13 layers at B=64: 680 tiles -> 456); time ~ rounds x BM.
+    if (t.bm == 128 && t.bn == 128 && t.bk == 64 && env_int("MCAMD_BM192", 1) &&
+        (ktot >= env_int("MCAMD_BM192_MINK", 4096) || env_int("MCAMD_BM192", 1) == 2)) {   // pays only when the K loop is long
+        const long long nt = (n + 127) / 128;
+        const long long t128 = ((M + 127) / 128) * nt, t192 = ((M + 191) / 192) * nt;
+        const long long cost128 = ((t128 + 511) / 512) * 128, cost192 = ((t192 + 511) / 512) * 192;
+        if (cost192 < cost128 || env_int("MCAMD_BM192", 1) == 2) t.bm = 192;
+    }
     return t;
 }
 
@@ -375,8 +386,8 @@ int mcamd_igemm_rows(long long M, int n, int cin_tap, int ktot) {
     return p;
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int NSTAGE>
-static void launch_one(const IgemmArgs& a, int rows, int ntiles, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int BK, int NSTAGE, int EPI>
+static void launch_inst(const IgemmArgs& a, int rows, int ntiles, hipStream_t st) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     constexpr int STAGE_BYTES = (BM + BN) * (BK / 8) * 16;
     size_t lds = NSTAGE * STAGE_BYTES;
@@ -384,11 +395,18 @@ static void launch_one(const IgemmArgs& a, int rows, int ntiles, hipStream_t st)
     if (lds < (size_t)(BM / WM) * 2 * BN * 4) lds = (size_t)(BM / WM) * 2 * BN * 4;
     static bool attr_set = false;
     if (lds > 64 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, BK, NSTAGE>,
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, BK, NSTAGE, EPI>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BK, NSTAGE>), dim3(round_up_int(rows, 8) * ntiles + 8), dim3(NT), lds, st, a);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BK, NSTAGE, EPI>), dim3(round_up_int(rows, 8) * ntiles + 8), dim3(NT), lds, st, a);
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int NSTAGE>
+static void launch_one(const IgemmArgs& a, int rows, int ntiles, hipStream_t st) {
+    if (a.mode == MCAMD_EPI_NCHW_F32) launch_inst<BM, BN, WM, WN, BK, NSTAGE, MCAMD_EPI_NCHW_F32>(a, rows, ntiles, st);
+    else if (a.mode == MCAMD_EPI_PAD_F16) launch_inst<BM, BN, WM, WN, BK, NSTAGE, MCAMD_EPI_PAD_F16>(a, rows, ntiles, st);
+    else launch_inst<BM, BN, WM, WN, BK, NSTAGE, MCAMD_EPI_RAW_F16>(a, rows, ntiles, st);
 }
 
 // a.* geometry fields must be filled by the caller; picks the tile and launches.
@@ -411,7 +429,8 @@ int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st) {
         done = true;                                                  \
     }
     bool done = false;
-    if (t.bm == 256 && t.bn == 256 && t.bk == 32) { launch_one<256, 256, 128, 64, 32, 4>(a, rows, ntiles, st); done = true; }
+    if (t.bm == 192 && t.bn == 128 && t.bk == 64) { launch_one<192, 128, 96, 64, 64, 2>(a, rows, ntiles, st); done = true; }
+    if (!done && t.bm == 256 && t.bn == 256 && t.bk == 32) { launch_one<256, 256, 128, 64, 32, 4>(a, rows, ntiles, st); done = true; }
     if (!done && t.bm == 256 && t.bn == 128 && t.bk == 32) { launch_one<256, 128, 64, 64, 32, 4>(a, rows, ntiles, st); done = true; }
     if (!done && t.bm == 256 && t.bn == 256) { launch_one<256, 256, 128, 64, 64, 2>(a, rows, ntiles, st); done = true; }
     if (!done && t.bm == 256 && t.bn == 128) { launch_one<256, 128, 64, 64, 64, 2>(a, rows, ntiles, st); done = true; }

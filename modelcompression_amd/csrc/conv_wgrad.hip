@@ -386,11 +386,24 @@ WgradPlan mcamd_wgrad_plan(long long M, int cout, int cin_tap, int ntaps) {
     p.n_ctiles = cin_tap / p.tnc;
     p.n_tapgroups = ntaps / p.taps;
     long long tiles = (long long)p.n_otiles * p.n_tapgroups * p.n_ctiles;
-    long long target = env_int_w("MCAMD_WGRAD_WGS", 1024);
-    long long ns = (target + tiles - 1) / tiles;
+    // Pixel splits: fill whole rounds of the machine.  `slots` workgroups run at once (3 per CU at the
+    // default 48 KB of LDS); time ~ rounds(ns) / ns, plus the slab traffic that grows with ns.
+    const long long slots = env_int_w("MCAMD_WGRAD_SLOTS", 768);
     long long max_by_work = (M + 8 * p.kp - 1) / (8 * p.kp);  // at least 8 steps per split
-    if (ns > max_by_work) ns = max_by_work;
-    if (ns < 1) ns = 1;
+    if (max_by_work < 1) max_by_work = 1;
+    long long cap = env_int_w("MCAMD_WGRAD_WGS", 3072) / tiles;
+    if (cap < 1) cap = 1;
+    if (cap > max_by_work) cap = max_by_work;
+    long long ns = 1;
+    double best = 1e30;
+    for (long long c = 1; c <= cap; ++c) {
+        double rounds = (double)((tiles * c + slots - 1) / slots);
+        double cost = rounds / (double)c * (1.0 + 0.004 * (double)c);
+        if (cost < best - 1e-12) {
+            best = cost;
+            ns = c;
+        }
+    }
     long long pps = ((M + ns - 1) / ns + p.kp - 1) / p.kp * p.kp;
     ns = (M + pps - 1) / pps;
     p.nsplit = (int)ns;
