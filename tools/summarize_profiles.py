@@ -5,8 +5,8 @@ src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_final"
 tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
 os.makedirs("profiles", exist_ok=True)
 def one(pat):
-    g = glob.glob(os.path.join(src, pat))
-    return g[0] if g else None
+    g = sorted(glob.glob(os.path.join(src, pat)), key=os.path.getmtime)   # newest run wins (gpurun merges runs)
+    return g[-1] if g else None
 st = one("stats/*/*kernel_stats.csv")
 shutil.copy(st, "profiles/%s_kernel_stats.csv" % tag)
 shutil.copy(os.path.join(src, "layer_table.txt"), "profiles/%s_layer_table.txt" % tag)
