@@ -21,8 +21,10 @@
  *     a tensor may be a channel slice [choff, choff+C) of a wider buffer -- that
  *     is how route/concat is expressed).  The pointer passed is the address of
  *     padded pixel (b=0, hp=0, wp=0), channel 0.  The halo must be zero and is
- *     never written by the library; buffers should be followed by >= 64 bytes of
- *     readable slack.
+ *     never written by the library.  Buffers must be preceded AND followed by a
+ *     zeroed guard band of (round_up(W+3, 4) + 32) pixels (+ 64 elements): the 9-tap
+ *     wgrad kernel reads whole row windows around its pixel chunk, and the stem
+ *     layer reads 32 contiguous halfs per pixel.
  *   raw conv output / gradient wrt a block output: fp16 [B*H*W][ld] (no halo).
  *   stem input (first layer, Cin = 3): padded NHWC with ld = 4 (channel 3 zero).
  *   packed weights: fp16 [Npad][K], see mcamd_pack_weights.

@@ -251,10 +251,15 @@ extern "C" int mcamd_conv_dgrad(const mcamd_conv_geom* g, const void* dy, int32_
 // ---------------------------------------------------------------------------------------
 // wgrad
 // ---------------------------------------------------------------------------------------
+static WgradPlan wgrad_plan_for(const mcamd_conv_geom* g) {
+    if (mcamd_wgrad_use9(g->ksize, g->stem, g->cout, cin_tap_of(g), g->W))
+        return mcamd_wgrad_plan9((long long)g->B * (g->H + 2) * (g->W + 2), g->cout, cin_tap_of(g));
+    return mcamd_wgrad_plan((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g), ntaps_of(g));
+}
+
 extern "C" size_t mcamd_conv_wgrad_workspace_bytes(const mcamd_conv_geom* g) {
     if (!g) return 0;
-    WgradPlan p = mcamd_wgrad_plan((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g), ntaps_of(g));
-    return p.bytes;
+    return wgrad_plan_for(g).bytes;
 }
 
 extern "C" int mcamd_conv_wgrad(const mcamd_conv_geom* g, const void* x, const void* dy, int32_t dy_ld, int32_t dy_choff,
@@ -266,7 +271,7 @@ extern "C" int mcamd_conv_wgrad(const mcamd_conv_geom* g, const void* x, const v
     (void)filter_keep;  // reserved: zero filters are already exact through the mask multiply
     const int cin_tap = cin_tap_of(g), ntaps = ntaps_of(g);
     const long long M = (long long)g->B * g->H * g->W;
-    WgradPlan p = mcamd_wgrad_plan(M, g->cout, cin_tap, ntaps);
+    WgradPlan p = wgrad_plan_for(g);
     MCAMD_REQUIRE(dy_ld % 8 == 0 && dy_choff % 8 == 0 && dy_choff + p.rows_pad <= dy_ld,
                   "conv_wgrad: dy slice [%d, %d) does not fit dy_ld %d", dy_choff, dy_choff + p.rows_pad, dy_ld);
     if (workspace_bytes < p.bytes) {
@@ -294,7 +299,8 @@ extern "C" int mcamd_conv_wgrad(const mcamd_conv_geom* g, const void* x, const v
     a.ntaps = ntaps;
     a.ktot = ntaps * cin_tap;
     fill_taps(g->ksize, g->stem, a.x_row_stride, g->x_ld, a.tap_off);
-    int rc = mcamd_wgrad_launch(a, p, st);
+    int rc = p.nine ? mcamd_wgrad9_launch(a, p, g->W, (long long)g->B * (g->H + 2) * (g->W + 2), st)
+                    : mcamd_wgrad_launch(a, p, st);
     if (rc) return rc;
     rc = mcamd_wgrad_finish_launch((const float*)workspace, p, a.ktot, cin_tap, g->stem, g->cout, g->cin, g->ksize,
                                    mask_oihw, 1.0f / grad_scale, dw_oihw, st);

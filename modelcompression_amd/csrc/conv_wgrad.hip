@@ -14,6 +14,7 @@
 // `self.weight * mask` followed by F.conv2d (reference layers.py:59-64).
 #include "kernels.h"
 #include <stdlib.h>
+#include <string.h>
 
 
 // 16-byte-chunk XOR swizzle of an LDS row of RB bytes so that the 4 rows one ds_read_b64_tr_b16
@@ -239,6 +240,132 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// 9-tap wgrad over PADDED pixels (3x3 layers with small images).
+//
+// Enumerating the padded pixels p' of dY (zero halo) makes every tap a constant row shift:
+//   dW[n][t][c] = sum_{p'} dY[p'][n] * X[p' + shift_t][c],  shift_t = (ty-1)*(W+2) + (tx-1)
+// (halo rows of dY are zero, so they add nothing).  One LDS window of X rows
+// [p0 - S, p0 + 32 + S), S >= W+3, therefore serves all nine taps, and the dY tile is shared by all
+// of them: ~2-3x fewer LDS-DMA bytes per flop than one tap per workgroup, and no pixel
+// decomposition at all (rows are linear in memory).  Price: the halo rows are multiplied too
+// (25 % at 13x13, 14 % at 26x26).  Workgroup = 64 filters x 64 input channels x 9 taps, wave
+// (i, j) owns the 32x32 block (i, j) for every tap (9 accumulators).
+struct Wgrad9Args {
+    const half_t* x;     // padded pixel (0,0,0), channel x_off; guard bands of >= S rows on both sides
+    const half_t* dy;    // padded pixel (0,0,0), channel dy_off
+    float* slab;
+    int x_ld, dy_ld, x_off, dy_off;
+    int W2;              // W + 2
+    int S;               // halo rows of the window on each side (multiple of 4, >= W + 3)
+    int P;               // number of padded pixels B*(H+2)*(W+2)
+    int rows_pad, ktot, cin_tap;
+    int n_ctiles, n_otiles, nsplit, steps_per_split, nsteps_total;
+};
+
+template <int RB>
+__device__ __forceinline__ h8_t tr_frag_rows(const char* tile, int row0, int colbase, int lane) {
+    // as tr_frag, but the 16 k-rows start at an arbitrary LDS row `row0` (+8 for the upper half-wave)
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+    const int row = row0 + 8 * (g >> 1) + q;
+    const int cb = colbase + 16 * (g & 1);
+    const int off = (cb + 4 * p) * 2;
+    const char* p0 = tile + row * RB + ((((off >> 4) ^ tr_swz<RB>(row)) << 4) | (off & 15));
+    const int row4 = row + 4;
+    const char* p1 = tile + row4 * RB + ((((off >> 4) ^ tr_swz<RB>(row4)) << 4) | (off & 15));
+    union {
+        fp16x4_t h[2];
+        h8_t v;
+    } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)p0);
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)p1);
+    return u.v;
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad9_kernel(Wgrad9Args a) {
+    constexpr int KP = 32, RB = 128, CH = 8;   // 64 channels = 128 bytes = 8 chunks per row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave & 1, wj = wave >> 1;
+    const int R = KP + 2 * a.S;                 // window rows (multiple of 8)
+    const int a_bytes = KP * RB, x_bytes = R * RB, stage_bytes = a_bytes + x_bytes;
+
+    const int ntiles = a.n_otiles * a.n_ctiles;
+    const int total_items = ntiles * a.nsplit;
+    const int chunk = (total_items + 7) >> 3;
+    const int item = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || item >= total_items) return;
+    const int split = item / ntiles;
+    const int tile = item - split * ntiles;
+    const int ot = tile / a.n_ctiles, ct = tile - ot * a.n_ctiles;
+    const int st0 = split * a.steps_per_split;
+    int st1 = st0 + a.steps_per_split;
+    if (st1 > a.nsteps_total) st1 = a.nsteps_total;
+
+    // DMA sources: row r of the dY tile is padded pixel p0 + r; row r of the X window is p0 - S + r
+    const int arow = tid >> 3, achunk = (tid & 7) ^ tr_swz<RB>(arow);
+    const half_t* dy_src = a.dy + a.dy_off + ot * 64 + achunk * 8 + (long long)arow * a.dy_ld;
+    const half_t* x_base = a.x + a.x_off + ct * 64 - (long long)a.S * a.x_ld;
+    const int x_iters = (R * CH + 255) >> 8;
+
+    f32x16_t acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    auto stage = [&](int st, int buf) {
+        const long long p0 = (long long)st * KP;
+        char* sa = smem + buf * stage_bytes;
+        char* sx = sa + a_bytes;
+        {
+            long long prow = p0 + arow;
+            const half_t* src = prow < a.P ? dy_src + p0 * a.dy_ld : a.dy + a.dy_off + ot * 64 + achunk * 8;  // pixel 0 = halo = 0
+            glds16(src, sa + wave * 1024);
+        }
+        for (int it = 0; it < x_iters; ++it) {
+            const int wslot = it * 256 + wave * 64;
+            if (wslot < R * CH) {
+                const int slot = wslot + lane;
+                const int row = slot >> 3, chunkx = (slot & 7) ^ tr_swz<RB>(row);
+                glds16(x_base + (p0 + row) * a.x_ld + chunkx * 8, sx + wslot * 16);
+            }
+        }
+    };
+
+    if (st1 > st0) stage(st0, 0);
+    for (int st = st0; st < st1; ++st) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (st + 1 < st1) stage(st + 1, (st + 1 - st0) & 1);
+        const char* sa = smem + ((st - st0) & 1) * stage_bytes;
+        const char* sx = sa + a_bytes;
+#pragma unroll
+        for (int s = 0; s < KP / 16; ++s) {
+            const h8_t af = tr_frag_rows<RB>(sa, 16 * s, wi * 32, lane);
+            h8_t bf[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int shift = (t / 3 - 1) * a.W2 + (t % 3 - 1);
+                bf[t] = tr_frag_rows<RB>(sx, 16 * s + a.S + shift, wj * 32, lane);
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[t], acc[t], 0, 0, 0);
+        }
+    }
+
+    float* out = a.slab + (long long)split * a.rows_pad * a.ktot;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int n = ot * 64 + wi * 32 + mfma32_row(r, lane);
+            int k = t * a.cin_tap + ct * 64 + wj * 32 + (lane & 31);
+            out[(long long)n * a.ktot + k] = acc[t][r];
+        }
+}
+
 // Sum the split slabs, apply mask and 1/grad_scale, write fp32 OIHW.  Deterministic: thread
 // (item, sg) sums the splits s = sg, sg+SG, ... in order, the SG partial sums are combined in
 // order through LDS.  SG grows with the split count so narrow layers (few weights, ~1000 pixel
@@ -375,8 +502,82 @@ static int pick_kp(int tmo, int tnc, int taps) {
     return 32;
 }
 
+static int wgrad9_S(int W) { return round_up_int(W + 3, 4); }
+
+// plan of the padded-pixel 9-tap kernel (see wgrad9_kernel); P = padded pixels
+static WgradPlan wgrad9_plan(long long P, int cout, int cin_tap) {
+    WgradPlan p;
+    memset(&p, 0, sizeof(p));
+    p.nine = 1;
+    p.tmo = p.tnc = 64;
+    p.taps = 9;
+    p.kp = 32;
+    p.rows_pad = round_up_int(cout, 64);
+    p.n_otiles = p.rows_pad / 64;
+    p.n_ctiles = cin_tap / 64;
+    p.n_tapgroups = 1;
+    long long tiles = (long long)p.n_otiles * p.n_ctiles;
+    long long nsteps = (P + 31) / 32;
+    const long long slots = env_int_w("MCAMD_WGRAD9_SLOTS", 512);
+    long long cap = env_int_w("MCAMD_WGRAD9_WGS", 2048) / tiles;
+    if (cap < 1) cap = 1;
+    if (cap > nsteps / 8) cap = nsteps / 8 > 0 ? nsteps / 8 : 1;
+    long long ns = 1;
+    double best = 1e30;
+    for (long long c = 1; c <= cap; ++c) {
+        double rounds = (double)((tiles * c + slots - 1) / slots);
+        double cost = rounds / (double)c * (1.0 + 0.004 * (double)c);
+        if (cost < best - 1e-12) {
+            best = cost;
+            ns = c;
+        }
+    }
+    long long sps = (nsteps + ns - 1) / ns;
+    ns = (nsteps + sps - 1) / sps;
+    p.nsplit = (int)ns;
+    p.pix_per_split = (int)(sps * 32);
+    p.bytes = (size_t)p.nsplit * p.rows_pad * ((size_t)9 * cin_tap) * sizeof(float);
+    return p;
+}
+
+bool mcamd_wgrad_use9(int ksize, int stem, int cout, int cin_tap, int W) {
+    return ksize == 3 && !stem && cin_tap % 64 == 0 && cout % 32 == 0 && round_up_int(cout, 64) == round_up_int(cout, 32) &&
+           W <= env_int_w("MCAMD_WGRAD9_MAXW", 208) && env_int_w("MCAMD_WGRAD9", 1);
+}
+
+WgradPlan mcamd_wgrad_plan9(long long P, int cout, int cin_tap) { return wgrad9_plan(P, cout, cin_tap); }
+
+int mcamd_wgrad9_launch(const WgradArgs& w, const WgradPlan& p, int W, long long P, hipStream_t st) {
+    Wgrad9Args a;
+    a.x = w.x;
+    a.dy = w.dy;
+    a.slab = w.slab;
+    a.x_ld = w.x_ld;
+    a.dy_ld = w.dy_ld;
+    a.x_off = w.x_off;
+    a.dy_off = w.dy_zero_off;          // padded pixel (0,0): the padded enumeration starts there
+    a.W2 = W + 2;
+    a.S = wgrad9_S(W);
+    a.P = (int)P;
+    a.rows_pad = p.rows_pad;
+    a.ktot = w.ktot;
+    a.cin_tap = w.cin_tap;
+    a.n_ctiles = p.n_ctiles;
+    a.n_otiles = p.n_otiles;
+    a.nsplit = p.nsplit;
+    a.steps_per_split = p.pix_per_split / 32;
+    a.nsteps_total = (int)((P + 31) / 32);
+    const int R = 32 + 2 * a.S;
+    size_t lds = 2 * (size_t)(32 * 128 + R * 128);
+    const int grid = round_up_int(p.n_otiles * p.n_ctiles * p.nsplit, 8);
+    hipLaunchKernelGGL(wgrad9_kernel, dim3(grid), dim3(256), lds, st, a);
+    MCAMD_LAUNCH_CHECK("wgrad9");
+    return MCAMD_OK;
+}
+
 WgradPlan mcamd_wgrad_plan(long long M, int cout, int cin_tap, int ntaps) {
     WgradPlan p;
+    p.nine = 0;
     p.tmo = pick_t(cout);
     p.tnc = pick_t(cin_tap);
     p.taps = pick_taps(p.tmo, p.tnc, ntaps);

@@ -24,9 +24,19 @@ def _need_cuda(*ts):
             raise L.McamdError("modelcompression_amd compute ops need CUDA (MI355X) tensors; there is no CPU path")
 
 
+def guard_elems(W, ld):
+    """Zeroed guard band (elements) in front of and behind every padded buffer: the 9-tap wgrad kernel
+    reads whole windows of (W+3, rounded up to 4) + 32 padded-pixel rows around its pixel chunk."""
+    return (round_up(W + 3, 4) + 32) * ld + SLACK
+
+
 def alloc_padded(B, H, W, ld, device):
-    """Zeroed padded-NHWC fp16 buffer [B][H+2][W+2][ld] (+ slack), flat."""
-    return torch.zeros(B * (H + 2) * (W + 2) * ld + SLACK, dtype=HALF, device=device)
+    """Zeroed padded-NHWC fp16 buffer [B][H+2][W+2][ld], flat, with zeroed guard bands on both sides
+    (the returned tensor is a view starting at padded pixel (0,0,0); its storage holds the guards)."""
+    n = B * (H + 2) * (W + 2) * ld
+    g = guard_elems(W, ld)
+    full = torch.zeros(g + n + g, dtype=HALF, device=device)
+    return full[g:g + n + SLACK]
 
 
 def padded_view(buf, B, H, W, ld):
