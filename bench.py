@@ -149,7 +149,7 @@ def main():
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
-            if tj["kernel"].startswith("void igemm_kernel<%d, %d," % dom_tile[:2]):
+            if tj["kernel"].startswith("void igemm9_kernel" if dom_tile[3] == 9 else "void igemm_kernel<%d, %d," % dom_tile[:2]):
                 traffic = round(tj["hbm_bytes_per_launch"])
         except Exception:
             traffic = None
@@ -175,7 +175,8 @@ def main():
         "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
                      "algorithmic_gflop_per_launch": round(dom_flop / max(dom_n, 1) / 1e9, 2),
-                     "kernel": "igemm_kernel<%d,%d,..,%d,2,0> (conv fwd + dgrad launches of that instance)" % dom_tile,
+                     "kernel": ("igemm9_kernel<0> 128x128x64 padded-pixel 9-tap (conv fwd + dgrad launches)" if dom_tile[3] == 9 else
+                                "igemm_kernel<%d,%d,..,%d,2,0> (conv fwd + dgrad launches of that instance)" % dom_tile[:3]),
                      "launches_per_step": dom_n // max(args.steps, 1),
                      "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4)},
     }

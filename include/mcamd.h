@@ -22,8 +22,8 @@
  *     is how route/concat is expressed).  The pointer passed is the address of
  *     padded pixel (b=0, hp=0, wp=0), channel 0.  The halo must be zero and is
  *     never written by the library.  Buffers must be preceded AND followed by a
- *     zeroed guard band of (round_up(W+3, 4) + 32) pixels (+ 64 elements): the 9-tap
- *     wgrad kernel reads whole row windows around its pixel chunk, and the stem
+ *     zeroed guard band of (round_up(W+3, 4) + 128) pixels (+ 64 elements): the 9-tap
+ *     kernels read whole row windows around their pixel tiles, and the stem
  *     layer reads 32 contiguous halfs per pixel.
  *   raw conv output / gradient wrt a block output: fp16 [B*H*W][ld] (no halo).
  *   stem input (first layer, Cin = 3): padded NHWC with ld = 4 (channel 3 zero).
@@ -88,9 +88,9 @@ typedef struct mcamd_conv_epilogue {
 /* Rows of the BatchNorm partial-sum slab a forward launch of this geometry writes. */
 int32_t mcamd_conv_stats_rows(const mcamd_conv_geom* g);
 
-/* Workgroup tile {BM, BN, BK} the forward (dgrad == 0) or dgrad launch of this geometry uses
- * (which igemm_kernel<BM,BN,..,BK> instance shows up in a profile). */
-int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int32_t out[3]);
+/* Workgroup tile {BM, BN, BK, kernel} the forward (dgrad == 0) or dgrad launch of this geometry uses:
+ * kernel 0 = igemm_kernel<BM,BN,..,BK,..> (one tap per K chunk), 9 = igemm9_kernel (padded-pixel 9-tap). */
+int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int32_t out[4]);
 
 /* Packed-weight sizes (elements of fp16) for a geometry. */
 int64_t mcamd_packed_elems_fwd(const mcamd_conv_geom* g);

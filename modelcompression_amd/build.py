@@ -20,6 +20,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno
 SOURCES = {
     "api.hip": [],
     "conv_igemm.hip": [],
+    "conv_igemm9.hip": [],
     "conv_wgrad.hip": [],
     "bn_act.hip": [],
     "prune.hip": ["-ffp-contract=off"],   # pinned fp32 arithmetic: no FMA contraction

@@ -146,7 +146,7 @@ extern "C" int mcamd_pack_weights(const mcamd_conv_geom* g, const float* w_oihw,
 // forward / dgrad
 // ---------------------------------------------------------------------------------------
 static int fill_epilogue(IgemmArgs& a, const mcamd_conv_epilogue* e, int n_out, long long M, int cin_tap, int ktot,
-                         const char* what) {
+                         const char* what, int expected_rows = -1) {
     MCAMD_REQUIRE(e && e->y, "%s: null output", what);
     a.y = e->y;
     a.mode = e->mode;
@@ -165,7 +165,7 @@ static int fill_epilogue(IgemmArgs& a, const mcamd_conv_epilogue* e, int n_out, 
         MCAMD_REQUIRE(e->y_ld % 8 == 0 && e->y_choff % 8 == 0 && e->y_choff + n_out <= e->y_ld,
                       "%s: output slice [%d, %d) does not fit y_ld %d", what, e->y_choff, e->y_choff + n_out, e->y_ld);
         if (e->mode == MCAMD_EPI_RAW_F16 && e->stats) {
-            int rows = mcamd_igemm_rows(M, n_out, cin_tap, ktot);
+            int rows = expected_rows >= 0 ? expected_rows : mcamd_igemm_rows(M, n_out, cin_tap, ktot);
             MCAMD_REQUIRE(e->stats_rows == rows, "%s: stats_rows must be mcamd_conv_stats_rows() = %d (got %d)", what, rows,
                           e->stats_rows);
             MCAMD_REQUIRE(e->stats_ld >= round_up_int(n_out, 256), "%s: stats_ld must be >= %d", what,
@@ -186,15 +186,46 @@ static int fill_epilogue(IgemmArgs& a, const mcamd_conv_epilogue* e, int n_out, 
 
 extern "C" int32_t mcamd_conv_stats_rows(const mcamd_conv_geom* g) {
     if (!g) return 0;
+    if (mcamd_igemm9_ok(g->ksize, g->stem, g->cout, cin_tap_of(g), g->W, MCAMD_EPI_RAW_F16))
+        return mcamd_igemm9_rows((long long)g->B * (g->H + 2) * (g->W + 2), g->cout);
     return mcamd_igemm_rows((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g), ntaps_of(g) * cin_tap_of(g));
 }
 
-extern "C" int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int32_t out[3]) {
+extern "C" int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int32_t out[4]) {
     if (check_geom(g, "conv_tile_info")) return MCAMD_EINVAL;
     MCAMD_REQUIRE(out, "conv_tile_info: null output");
+    out[3] = 0;
+    if (mcamd_igemm9_ok(g->ksize, g->stem, dgrad ? g->cin : g->cout, dgrad ? cout_p_of(g) : cin_tap_of(g), g->W,
+                        MCAMD_EPI_RAW_F16)) {
+        out[0] = 128, out[1] = 128, out[2] = 64, out[3] = 9;   // igemm9_kernel (padded-pixel 9-tap)
+        return MCAMD_OK;
+    }
     mcamd_igemm_tile((long long)g->B * g->H * g->W, dgrad ? g->cin : g->cout, dgrad ? cout_p_of(g) : cin_tap_of(g),
                      dgrad ? g->ksize * g->ksize * cout_p_of(g) : ntaps_of(g) * cin_tap_of(g), out);
     return MCAMD_OK;
+}
+
+// 3x3 layers on small images go through the padded-pixel 9-tap kernel (conv_igemm9.hip)
+static int launch_igemm9(const IgemmArgs& a, const mcamd_conv_geom* g, hipStream_t st) {
+    Igemm9Args q;
+    memset(&q, 0, sizeof(q));
+    q.x = a.x;
+    q.w = a.w;
+    q.y = a.y;
+    q.stats = a.stats;
+    q.scale = a.scale;
+    q.shift = a.shift;
+    q.x_ld = a.x_ld;
+    q.x_off = a.x_off;
+    q.H = g->H, q.W = g->W, q.W2 = g->W + 2, q.HW2 = (g->H + 2) * (g->W + 2);
+    q.S = mcamd_igemm9_S(g->W);
+    q.P = g->B * q.HW2;
+    q.N = a.N;
+    q.ktot = a.ktot;
+    q.cin_tap = a.cin_tap;
+    q.mode = a.mode, q.y_ld = a.y_ld, q.y_choff = a.y_choff, q.stats_ld = a.stats_ld;
+    q.slope = a.slope;
+    return mcamd_igemm9_launch(q, st);
 }
 
 extern "C" int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const void* wp_fwd, const mcamd_conv_epilogue* epi,
@@ -216,7 +247,11 @@ extern "C" int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const voi
     a.ntaps = ntaps_of(g);
     a.ktot = a.ntaps * a.cin_tap;
     fill_taps(g->ksize, g->stem, a.x_row_stride, g->x_ld, a.tap_off);
-    if (fill_epilogue(a, epi, g->cout, a.M, a.cin_tap, a.ktot, "conv_fwd")) return MCAMD_EINVAL;
+    const bool nine = epi && mcamd_igemm9_ok(g->ksize, g->stem, g->cout, a.cin_tap, g->W, epi->mode);
+    if (fill_epilogue(a, epi, g->cout, a.M, a.cin_tap, a.ktot, "conv_fwd",
+                      nine ? mcamd_igemm9_rows((long long)g->B * (g->H + 2) * (g->W + 2), g->cout) : -1))
+        return MCAMD_EINVAL;
+    if (nine) return launch_igemm9(a, g, (hipStream_t)stream);
     return mcamd_igemm_launch(a, (hipStream_t)stream);
 }
 
@@ -245,6 +280,7 @@ extern "C" int mcamd_conv_dgrad(const mcamd_conv_geom* g, const void* dy, int32_
     fill_taps(g->ksize, 0, a.x_row_stride, dy_ld, a.tap_off);
     MCAMD_REQUIRE(epi && epi->mode != MCAMD_EPI_PAD_F16 && !epi->stats, "conv_dgrad: epilogue must be mode 0 (no stats) or 1");
     if (fill_epilogue(a, epi, g->cin, a.M, a.cin_tap, a.ktot, "conv_dgrad")) return MCAMD_EINVAL;
+    if (mcamd_igemm9_ok(g->ksize, 0, g->cin, a.cin_tap, g->W, epi->mode)) return launch_igemm9(a, g, (hipStream_t)stream);
     return mcamd_igemm_launch(a, (hipStream_t)stream);
 }
 

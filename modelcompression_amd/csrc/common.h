@@ -48,3 +48,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+
+// XOR swizzle of the 16-byte chunks of an LDS row of CPR chunks (ds_read_b128 operand tiles).
+template <int CPR>
+__device__ __forceinline__ int swz(int row) {
+    // CPR = 16-byte chunks per LDS row.  64-byte rows: 4 rows span the 64 banks -> XOR with
+    // (row>>2)&3; 128-byte rows: 2 rows span them -> XOR with (row>>1)&7.  Either makes the 16
+    // lanes of every ds_read_b128 lane group hit 16 distinct 16-byte slots.
+    return CPR == 4 ? ((row >> 2) & 3) : ((row >> 1) & 7);
+}
+

@@ -23,14 +23,6 @@
 #include <stdlib.h>
 
 
-template <int CPR>
-__device__ __forceinline__ int swz(int row) {
-    // CPR = 16-byte chunks per LDS row.  64-byte rows: 4 rows span the 64 banks -> XOR with
-    // (row>>2)&3; 128-byte rows: 2 rows span them -> XOR with (row>>1)&7.  Either makes the 16
-    // lanes of every ds_read_b128 lane group hit 16 distinct 16-byte slots.
-    return CPR == 4 ? ((row >> 2) & 3) : ((row >> 1) & 7);
-}
-
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

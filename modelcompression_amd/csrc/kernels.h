@@ -29,6 +29,23 @@ struct IgemmArgs {
     int xcd_order;
 };
 
+struct Igemm9Args {
+    const half_t* x;      // padded pixel (0,0,0), channel 0 of the buffer (x_off added in the kernel)
+    const half_t* w;      // packed weights [Npad][9*cin_tap]
+    void* y;
+    float* stats;
+    const float* scale;
+    const float* shift;
+    int x_ld, x_off;
+    int H, W, W2, HW2;    // real size, W+2, (H+2)*(W+2)
+    int S;                // halo rows of the activation window (multiple of 4, >= W+3)
+    int P;                // padded pixels B*(H+2)*(W+2)
+    int N, ktot, cin_tap;
+    int mode, y_ld, y_choff, stats_ld;
+    float slope;
+    int num_mtiles, num_pslots, num_ntiles;
+};
+
 struct WgradArgs {
     const half_t* x;
     const half_t* dy;
@@ -66,3 +83,8 @@ int mcamd_wgrad_finish_launch(const float* slab, const WgradPlan& p, int ktot, i
                               int ksize, const float* mask, float inv_scale, float* dw, hipStream_t st);
 int mcamd_colsum_launch(const half_t* dy, long long rows, int ld, int choff, int C, float inv_scale, float* out,
                         hipStream_t st);
+
+bool mcamd_igemm9_ok(int ksize, int stem, int n, int cin_tap, int W, int mode);
+int mcamd_igemm9_S(int W);
+int mcamd_igemm9_rows(long long P, int n);
+int mcamd_igemm9_launch(Igemm9Args& a, hipStream_t st);

@@ -26,8 +26,9 @@ def _need_cuda(*ts):
 
 def guard_elems(W, ld):
     """Zeroed guard band (elements) in front of and behind every padded buffer: the 9-tap wgrad kernel
-    reads whole windows of (W+3, rounded up to 4) + 32 padded-pixel rows around its pixel chunk."""
-    return (round_up(W + 3, 4) + 32) * ld + SLACK
+    and the 9-tap forward/dgrad kernels read whole windows of (W+3 rounded up to 4) padded-pixel
+    rows around their 32- / 128-row pixel tiles."""
+    return (round_up(W + 3, 4) + 128) * ld + SLACK
 
 
 def alloc_padded(B, H, W, ld, device):
@@ -68,7 +69,7 @@ def pack_weights(g, w, mask=None, want_fwd=True, want_dgrad=True, out_fwd=None, 
 
 
 def tile_info(g, dgrad=False):
-    out = (C.c_int32 * 3)()
+    out = (C.c_int32 * 4)()
     check(L.lib().mcamd_conv_tile_info(C.byref(g), 1 if dgrad else 0, out), "mcamd_conv_tile_info")
     return tuple(out)
 
