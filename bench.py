@@ -108,6 +108,8 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     events, eng.events = eng.events, None
+    flat = model._last_flat_grad
+    assert flat is not None and bool(torch.isfinite(flat).all()), "non-finite gradients in the timed run"
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -125,7 +125,7 @@ def test_mini_masked_training_steps(dev):
     assert prune_rate(m, verbose=False) > 50.0
 
 
-def _teacher_forced(dev, cfg, B, seed, masked, hw=None):
+def _teacher_forced(dev, cfg, B, seed, masked, hw=None, only=None):
     """Every kernel of a training step, at the network's real shapes, against fp32 torch-CPU math
     fed with the ENGINE'S OWN inputs for that kernel (so errors cannot compound)."""
     import torch.nn.functional as F
@@ -154,12 +154,17 @@ def _teacher_forced(dev, cfg, B, seed, masked, hw=None):
         assert val < tol, "%s of conv block %d: %.3e >= %.1e" % (name, lay.index, val, tol)
 
     for lay in eng.layers:
+        if only is not None and lay.li + 1 not in only:
+            continue
         t = lay.tin
         X = padded_to_nchw(eng.bufs[t.buf], B, t.H, t.W, t.ld, t.C, t.choff)
         w = lay.conv.weight.detach().cpu()
         mask = lay.conv.mask.cpu() if lay.conv.mask_flag else None
-        wq = (w * mask if mask is not None else w).half().float().requires_grad_(True)
-        Xl = X.clone().requires_grad_(True)
+        # at the bench's batch the reductions run over up to 11 M pixels: an fp32 CPU reference is itself
+        # only good to ~1e-3 there, so the reference conv is evaluated in float64
+        rdt = torch.float64 if B >= 16 else torch.float32
+        wq = (w * mask if mask is not None else w).half().to(rdt).requires_grad_(True)
+        Xl = X.clone().to(rdt).requires_grad_(True)
         yref = F.conv2d(Xl, wq, None, 1, (lay.k - 1) // 2)
         if lay.is_last:
             rec("logits", rel_l2(out.detach().cpu(), yref.detach() + lay.conv.bias.detach().cpu().view(1, -1, 1, 1)), 1e-3, lay)
@@ -194,7 +199,7 @@ def _teacher_forced(dev, cfg, B, seed, masked, hw=None):
             rec("dgamma", rel_l2(lay.bn.weight.grad.cpu(), gam.grad), 2e-3, lay)
             rec("dbeta", rel_l2(lay.bn.bias.grad.cpu(), bet.grad), 2e-3, lay)
         # wgrad / dgrad from the engine's dY
-        yref.backward(dy)
+        yref.backward(dy.to(rdt))
         gw = wq.grad * mask if mask is not None else wq.grad
         rec("wgrad", rel_l2(lay.conv.weight.grad.cpu(), gw), 1e-3, lay)
         if mask is not None:
@@ -214,6 +219,12 @@ def test_layerwise_teacher_forced_mini(dev):
 def test_layerwise_teacher_forced_nonsquare_odd_batch(dev):
     """The engine follows the input's shape, not the cfg's: non-square image, batch 3, ragged tiles."""
     _teacher_forced(dev, MINI, 3, 9, masked=False, hw=(96, 160))
+
+
+def test_layerwise_teacher_forced_b64_selected(dev):
+    """The bench's batch (B=64: 11 M output pixels in conv1, 0.7 GB tensors) on selected layers --
+    guards the 32/64-bit index arithmetic of every kernel at real sizes."""
+    _teacher_forced(dev, YOLOV2_VOC_CFG, 64, 6, masked=False, only={1, 2, 14, 22, 23})
 
 
 def test_layerwise_teacher_forced_yolov2(dev):
