@@ -149,6 +149,12 @@ typedef struct mcamd_act_desc {
     int32_t mode;              /* MCAMD_DST_* for dst */
     void* dst; int32_t dst_ld, dst_choff;   /* padded NHWC fp16 at the mode's resolution */
     void* dst2; int32_t dst2_ld, dst2_choff;/* optional second copy, PLAIN resolution (route of a pooled layer) */
+    const float* border;       /* optional fp32 [16][C], NULL = none: added to the raw conv output before the
+                                  affine step, row = border class of the pixel (bit 0: h == 0, bit 1: h == H-1,
+                                  bit 2: w == 0, bit 3: w == W-1).  Physically slim filter-pruned models fold the
+                                  constant output of their removed input channels into this table, because zero
+                                  padding clips it differently at the borders (BASELINE config 5; the reference
+                                  only states slim convs as a conclusion, README.md:19). */
 } mcamd_act_desc;
 int mcamd_bn_act_fwd(const mcamd_act_desc* d, void* stream);
 

@@ -32,7 +32,8 @@ class ActDesc(C.Structure):
                 ("y", C.c_void_p), ("y_ld", C.c_int32), ("y_choff", C.c_int32),
                 ("scale", C.c_void_p), ("shift", C.c_void_p), ("slope", C.c_float), ("mode", C.c_int32),
                 ("dst", C.c_void_p), ("dst_ld", C.c_int32), ("dst_choff", C.c_int32),
-                ("dst2", C.c_void_p), ("dst2_ld", C.c_int32), ("dst2_choff", C.c_int32)]
+                ("dst2", C.c_void_p), ("dst2_ld", C.c_int32), ("dst2_choff", C.c_int32),
+                ("border", C.c_void_p)]
 
 
 class ActBwdDesc(C.Structure):

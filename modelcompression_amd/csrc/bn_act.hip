@@ -69,6 +69,7 @@ struct ActArgs {
     int y_ld, y_choff, dst_ld, dst_choff, dst2_ld, dst2_choff;
     float slope;
     long long items;
+    const float* border;  // optional [16][C]: added to the raw conv output by border class (slim models)
 };
 
 __device__ __forceinline__ void load8(const half_t* p, float* v) {
@@ -97,22 +98,42 @@ __device__ __forceinline__ long long pad_off(int b, int h, int w, int H, int W, 
     return (((long long)b * (H + 2) + h + 1) * (W + 2) + w + 1) * ld;
 }
 
-template <int MODE>
+// Border class of pixel (h, w): which 3x3 taps fall into the zero padding (bit 0 top, 1 bottom, 2 left, 3 right).
+__device__ __forceinline__ int border_class(int h, int w, int H, int W) {
+    return (h == 0 ? 1 : 0) | (h == H - 1 ? 2 : 0) | (w == 0 ? 4 : 0) | (w == W - 1 ? 8 : 0);
+}
+
+// FIXED: C/8 divides 256, so a thread keeps one channel group for the whole grid-stride loop and its BN
+// coefficients stay in registers.  !FIXED: any C % 8 == 0 (slim models), coefficients re-read per item (L1/L2 hits).
+template <int MODE, bool FIXED>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(ActArgs a) {
     const int CH = a.C >> 3;
-    const int c8 = (threadIdx.x % CH) * 8;  // fixed per thread: 256 % CH == 0 and the stride is a multiple of 256
+    int c8 = (threadIdx.x % CH) * 8;
     float sc[8], sh[8];
-    loadf8(a.scale + c8, sc);
-    loadf8(a.shift + c8, sh);
+    if (FIXED) {
+        loadf8(a.scale + c8, sc);
+        loadf8(a.shift + c8, sh);
+    }
     const int Ho = a.H >> 1, Wo = a.W >> 1;
     for (long long item = (long long)blockIdx.x * 256 + threadIdx.x; item < a.items; item += (long long)gridDim.x * 256) {
         long long pix = item / CH;
+        if (!FIXED) {
+            c8 = (int)(item - pix * CH) * 8;
+            loadf8(a.scale + c8, sc);
+            loadf8(a.shift + c8, sh);
+        }
         if (MODE == MCAMD_DST_PLAIN) {
             int b = (int)(pix / (a.H * a.W));
             int rem = (int)(pix - (long long)b * a.H * a.W);
             int h = rem / a.W, w = rem - h * a.W;
             float v[8];
             load8(a.y + pix * a.y_ld + a.y_choff + c8, v);
+            if (a.border) {
+                float bb[8];
+                loadf8(a.border + border_class(h, w, a.H, a.W) * a.C + c8, bb);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += bb[i];
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float z = v[i] * sc[i] + sh[i];
@@ -129,6 +150,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(ActArgs a) {
                 int h = 2 * ho + (k >> 1), w = 2 * wo + (k & 1);
                 long long sp = ((long long)b * a.H + h) * a.W + w;
                 load8(a.y + sp * a.y_ld + a.y_choff + c8, act[k]);
+                if (a.border) {
+                    float bb[8];
+                    loadf8(a.border + border_class(h, w, a.H, a.W) * a.C + c8, bb);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) act[k][i] += bb[i];
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     float z = act[k][i] * sc[i] + sh[i];
@@ -398,7 +425,7 @@ static int check_c(int C, const char* what) {
 
 extern "C" int mcamd_bn_act_fwd(const mcamd_act_desc* d, void* stream) {
     MCAMD_REQUIRE(d && d->y && d->dst && d->scale && d->shift, "bn_act_fwd: null argument");
-    if (check_c(d->C, "bn_act_fwd")) return MCAMD_EINVAL;
+    MCAMD_REQUIRE(d->C > 0 && d->C % 8 == 0, "bn_act_fwd: channel count %d must be a positive multiple of 8", d->C);
     MCAMD_REQUIRE(d->y_ld % 8 == 0 && d->y_choff % 8 == 0 && d->dst_ld % 8 == 0 && d->dst_choff % 8 == 0 &&
                       d->dst2_ld % 8 == 0 && d->dst2_choff % 8 == 0,
                   "bn_act_fwd: leading dimensions / channel offsets must be multiples of 8");
@@ -419,10 +446,19 @@ extern "C" int mcamd_bn_act_fwd(const mcamd_act_desc* d, void* stream) {
     a.items = pixels * (d->C / 8);
     int grid = stream_grid(a.items);
     hipStream_t st = (hipStream_t)stream;
-    if (d->mode == MCAMD_DST_PLAIN) hipLaunchKernelGGL(bn_act_fwd_kernel<MCAMD_DST_PLAIN>, dim3(grid), dim3(256), 0, st, a);
-    else if (d->mode == MCAMD_DST_POOL) hipLaunchKernelGGL(bn_act_fwd_kernel<MCAMD_DST_POOL>, dim3(grid), dim3(256), 0, st, a);
-    else if (d->mode == MCAMD_DST_REORG) hipLaunchKernelGGL(bn_act_fwd_kernel<MCAMD_DST_REORG>, dim3(grid), dim3(256), 0, st, a);
+    a.border = d->border;
+    const int CH = d->C / 8;
+    const bool fixed = CH <= 256 && 256 % CH == 0;
+#define ACT_CASE(MODE_)                                                                                         \
+    do {                                                                                                        \
+        if (fixed) hipLaunchKernelGGL((bn_act_fwd_kernel<MODE_, true>), dim3(grid), dim3(256), 0, st, a);       \
+        else hipLaunchKernelGGL((bn_act_fwd_kernel<MODE_, false>), dim3(grid), dim3(256), 0, st, a);            \
+    } while (0)
+    if (d->mode == MCAMD_DST_PLAIN) ACT_CASE(MCAMD_DST_PLAIN);
+    else if (d->mode == MCAMD_DST_POOL) ACT_CASE(MCAMD_DST_POOL);
+    else if (d->mode == MCAMD_DST_REORG) ACT_CASE(MCAMD_DST_REORG);
     else MCAMD_REQUIRE(false, "bn_act_fwd: bad mode %d", d->mode);
+#undef ACT_CASE
     MCAMD_LAUNCH_CHECK("bn_act_fwd");
     return MCAMD_OK;
 }

@@ -20,6 +20,8 @@ Activations live in HBM as padded NHWC fp16 for the whole step; weights are re-p
 (fp32 master * mask -> fp16) once per optimizer step.  All buffers are allocated once per
 batch size; a B=64 training step holds ~7 GB of the 288 GB.
 """
+import os
+
 import torch
 
 from . import ops
@@ -63,6 +65,9 @@ class Engine:
         self.serial = 0
         self._packed_sig = None
         self.events = None            # list of (tag, layer, start, end) HIP events while profiling
+        # MCAMD_OVERLAP_WGRAD=1: weight-gradient kernels on a second HIP stream beside the dgrad chain
+        self.overlap_wgrad = os.environ.get("MCAMD_OVERLAP_WGRAD", "0") == "1"
+        self._side_stream = None
         self._build_plan(H, W)
 
     # ------------------------------------------------------------------ plan
@@ -198,8 +203,23 @@ class Engine:
                 if lay.slope != 1.0 or consumers.get(ci):
                     raise NotImplementedError("a conv block without batch_normalize must be the final linear block")
             else:
-                if lay.cout % 8 or 256 % (lay.cout // 8):
-                    raise NotImplementedError("BN channel count %d (needs 8 * power of two)" % lay.cout)
+                if lay.cout % 8:
+                    raise NotImplementedError("BN channel count %d (needs a multiple of 8)" % lay.cout)
+            # the BN backward kernels keep one channel group per thread: 8 * (power of two) channels
+            lay.train_ok = lay.is_last or (lay.cout // 8 <= 256 and 256 % (lay.cout // 8) == 0)
+            # slim models (slim.py): constant contribution of physically removed input channels, by border class
+            lay.border = getattr(lay.conv, "border_bias", None)
+            lay.border_map = None
+            if lay.border is not None:
+                lay.border = lay.border.detach().to(device=dev, dtype=torch.float32).contiguous()
+                if tuple(lay.border.shape) != (16, lay.cout):
+                    raise McamdError("conv block %d: border_bias must be [16, %d]" % (ci, lay.cout))
+                if lay.is_last:      # the fp32 NCHW epilogue has no table: added to the logits as a [1,C,H,W] map
+                    hh = torch.arange(lay.H, device=dev)
+                    ww = torch.arange(lay.W, device=dev)
+                    cls = ((hh == 0).long() + 2 * (hh == lay.H - 1).long())[:, None] + \
+                          (4 * (ww == 0).long() + 8 * (ww == lay.W - 1).long())[None, :]
+                    lay.border_map = lay.border[cls.reshape(-1)].t().reshape(1, lay.cout, lay.H, lay.W).contiguous()
             by_src.setdefault(src, []).append(lay)
             self.layers.append(lay)
         for s, ls in by_src.items():
@@ -295,6 +315,13 @@ class Engine:
         B = self.B
         if tuple(x.shape) != (B, self.layers[0].cin, self.layers[0].H, self.layers[0].W):
             raise McamdError("engine built for input %s, got %s" % ((B, self.layers[0].cin, self.layers[0].H, self.layers[0].W), tuple(x.shape)))
+        if training:
+            for lay in self.layers:
+                if lay.border is not None:
+                    raise McamdError("slim models (border_bias tables) are inference-only: call model.eval()")
+                if not lay.train_ok:
+                    raise McamdError("conv block %d: training needs a BN channel count of 8 * (power of two), got %d"
+                                     % (lay.index, lay.cout))
         self.pack(force=training)
         self.serial += 1
         tin = self.layers[0].tin
@@ -305,6 +332,8 @@ class Engine:
             if lay.is_last:
                 bias = lay.conv.bias.data if lay.conv.bias is not None else None
                 self._timed('fwd', lay, ops.conv_fwd_nchw, lay.geom, xin, lay.wp, out, bias)
+                if lay.border_map is not None:
+                    out += lay.border_map
                 continue
             bn = lay.bn
             self._timed('fwd', lay, ops.conv_fwd_raw, lay.geom, xin, lay.wp, lay.y, lay.cout, 0, lay.stats if training else None)
@@ -315,7 +344,7 @@ class Engine:
             ops.bn_act_fwd(B, lay.H, lay.W, lay.cout, lay.y, lay.cout, 0, lay.scale, lay.shift, lay.slope, lay.mode,
                            self.bufs[t.buf], t.ld, t.choff,
                            self.bufs[t2.buf] if t2 is not None else None,
-                           t2.ld if t2 is not None else 0, t2.choff if t2 is not None else 0)
+                           t2.ld if t2 is not None else 0, t2.choff if t2 is not None else 0, border=lay.border)
         if training:
             bns = [lay.bn.num_batches_tracked for lay in self.layers if lay.bn is not None]
             if bns:
@@ -330,6 +359,13 @@ class Engine:
         flat = torch.empty(self.total_params, dtype=torch.float32, device=self.device)
         views = [flat[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.params)]
         gmap = {id(p): v for p, v in zip(self.params, views)}
+        side = main = None
+        if self.overlap_wgrad:
+            main = torch.cuda.current_stream(self.device)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(self.device)
+            side = self._side_stream
+            flat.record_stream(side)
         for lay in reversed(self.layers):
             if lay.is_last:
                 ops.nchw_to_padded(grad_out.detach().contiguous().float(), lay.dy, lay.cout_p, 0, S)
@@ -346,10 +382,22 @@ class Engine:
                                self.bwd_ws, lay.keep)
             mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
             dbias = gmap[id(lay.conv.bias)] if lay.conv.bias is not None else None
-            self._timed('wgrad', lay, ops.conv_wgrad, lay.geom, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
-                        gmap[id(lay.conv.weight)], mask, S, dbias, self.wgrad_ws)
+            if side is None:
+                self._timed('wgrad', lay, ops.conv_wgrad, lay.geom, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
+                            gmap[id(lay.conv.weight)], mask, S, dbias, self.wgrad_ws)
+            else:
+                # dY of this block is complete on the main stream: the weight gradient (which nothing in the
+                # backward chain depends on) runs beside the dgrad / BN-backward chain and fills its tails
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    self._timed('wgrad', lay, ops.conv_wgrad, lay.geom, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
+                                gmap[id(lay.conv.weight)], mask, S, dbias, self.wgrad_ws)
             if lay.li > 0:
                 # gradient wrt this block's input slice, written into gin at the slice's channel offset
                 self._timed('dgrad', lay, ops.conv_dgrad_raw, lay.geom, lay.dy, lay.cout_p, 0, lay.wd, lay.gin, lay.tin.ld,
                             lay.tin.choff)
+        if side is not None:
+            main.wait_stream(side)
         return flat, views

@@ -143,7 +143,8 @@ def bn_coeffs(stats, C_, count, gamma, beta, rmean, rvar, training, scale, shift
 
 
 def bn_act_fwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, slope, mode, dst, dst_ld, dst_choff=0, dst2=None,
-               dst2_ld=0, dst2_choff=0):
+               dst2_ld=0, dst2_choff=0, border=None):
+    """`border`: optional fp32 [16, C] table added to the raw conv output by border class (slim models)."""
     d = ActDesc()
     d.B, d.H, d.W, d.C = B, H, W, C_
     d.y, d.y_ld, d.y_choff = y.data_ptr(), y_ld, y_choff
@@ -151,6 +152,10 @@ def bn_act_fwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, slope, mode, dst, ds
     d.dst, d.dst_ld, d.dst_choff = dst.data_ptr(), dst_ld, dst_choff
     d.dst2 = dst2.data_ptr() if dst2 is not None else None
     d.dst2_ld, d.dst2_choff = dst2_ld, dst2_choff
+    if border is not None:
+        if border.dtype != torch.float32 or tuple(border.shape) != (16, C_) or not border.is_contiguous():
+            raise L.McamdError("bn_act_fwd: border table must be contiguous fp32 [16, %d]" % C_)
+        d.border = border.data_ptr()
     check(L.lib().mcamd_bn_act_fwd(C.byref(d), stream_ptr()), "mcamd_bn_act_fwd")
 
 

@@ -170,7 +170,15 @@ class _GradFp16(torch.autograd.Function):
         return g.half().float()
 
 
-def forward(blocks, state, x, training=False, masks=None, record=None, conv_out=None, storage=None):
+def border_map(table, H, W):
+    """[16, C] border-class table -> [1, C, H, W] (class bits: 1 top row, 2 bottom row, 4 left column,
+    8 right column; include/mcamd.h `mcamd_act_desc.border`)."""
+    hh, ww = torch.arange(H), torch.arange(W)
+    cls = ((hh == 0).long() + 2 * (hh == H - 1).long())[:, None] + (4 * (ww == 0).long() + 8 * (ww == W - 1).long())[None, :]
+    return table[cls.reshape(-1)].t().reshape(1, table.shape[1], H, W)
+
+
+def forward(blocks, state, x, training=False, masks=None, record=None, conv_out=None, storage=None, border=None):
     """Returns the last conv block's output (the region block is skipped,
     nets.py:761-762).  `masks`: list indexed by conv order, applied as
     `weight * mask` (layers.py:59).  `record`: dict filled with every block
@@ -182,7 +190,10 @@ def forward(blocks, state, x, training=False, masks=None, record=None, conv_out=
     gradients flowing back through them) is rounded to fp16 at that point.  Comparing the
     engine with THIS run isolates kernel errors from the (ill-conditioned) response of a
     BatchNorm/LeakyReLU network to fp16 rounding; comparing this run with the plain fp32
-    run measures that response."""
+    run measures that response.
+
+    `border`: {conv id: [16, Cout] table} added to the raw conv output by border class -- the slim
+    (physically filter-pruned) models of modelcompression_amd/slim.py; no reference counterpart."""
     q = (lambda t: _StoreFp16.apply(t)) if storage == "fp16" else (lambda t: t)
     outputs, ci = {}, 0
     if storage == "fp16":
@@ -199,6 +210,8 @@ def forward(blocks, state, x, training=False, masks=None, record=None, conv_out=
                 w = w + (w.half().float() - w).detach()      # fp16 operand, fp32 master gradient
             bias = None if op["bn"] else state[p + "conv%d.bias" % i]
             x = F.conv2d(x, w, bias, op["stride"], op["pad"], 1, 1)
+            if border is not None and i in border:       # slim models: folded constant input channels
+                x = x + border_map(border[i].to(x.dtype), x.shape[2], x.shape[3])
             if storage == "fp16":
                 x = q(x) if op["bn"] else _GradFp16.apply(x)  # logits leave in fp32; their gradient arrives as fp16
             if conv_out is not None:
