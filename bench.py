@@ -114,6 +114,13 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # every rank must hold the same averaged gradient and the same weights after the same steps
+        sig = torch.stack([flat.double().sum(), flat.double().abs().sum(),
+                           sum(p.detach().double().sum() for p in model.parameters())])
+        lo, hi = sig.clone(), sig.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert bool((lo == hi).all()), "ranks diverged: gradient / weight checksums differ (%s vs %s)" % (lo.tolist(), hi.tolist())
 
     # ---- roofline of the dominant kernel: igemm_kernel<128,128,64,64,BK> (fwd + dgrad launches)
     per = {}

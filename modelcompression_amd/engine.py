@@ -264,6 +264,22 @@ class Engine:
             self.offsets.append(off)
             off += p.numel()
         self.total_params = off
+        # slice of the flat gradient each conv block owns (its conv + BN parameters are adjacent in
+        # model.parameters(), nets.py:798-815): [p_lo, p_hi) tile [0, total) in layer order
+        offs = {id(p): (o, p.numel()) for p, o in zip(self.params, self.offsets)}
+        for lay in self.layers:
+            own = [lay.conv.weight] + ([lay.conv.bias] if lay.conv.bias is not None else [])
+            if lay.bn is not None:
+                own += [lay.bn.weight, lay.bn.bias]
+            lay.p_lo = min(offs[id(p)][0] for p in own)
+            lay.p_hi = max(offs[id(p)][0] + offs[id(p)][1] for p in own)
+        edge = 0
+        for lay in self.layers:
+            if lay.p_lo != edge:
+                raise NotImplementedError("parameters outside the conv blocks (offset %d)" % edge)
+            edge = lay.p_hi
+        if edge != off:
+            raise NotImplementedError("parameters outside the conv blocks (tail)")
         self.out_shape = (B, self.layers[-1].cout, self.layers[-1].H, self.layers[-1].W)
 
     # ------------------------------------------------------------------ per-kernel timing
@@ -352,8 +368,11 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ backward
-    def backward(self, grad_out):
-        """grad wrt the returned logits -> one flat fp32 gradient buffer; returns per-parameter views."""
+    def backward(self, grad_out, on_ready=None):
+        """grad wrt the returned logits -> one flat fp32 gradient buffer; returns per-parameter views.
+        `on_ready(flat, lo, hi)` is called as soon as every kernel writing flat[lo:hi] is enqueued
+        (layers finish last-to-first, so the slices walk down from the tail): dp.GradReducer
+        starts its all-reduce buckets there."""
         S = self.grad_scale
         # every element is written below (wgrad finish / dgamma / dbeta / dbias): no memset needed
         flat = torch.empty(self.total_params, dtype=torch.float32, device=self.device)
@@ -394,6 +413,8 @@ class Engine:
                 with torch.cuda.stream(side):
                     self._timed('wgrad', lay, ops.conv_wgrad, lay.geom, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
                                 gmap[id(lay.conv.weight)], mask, S, dbias, self.wgrad_ws)
+            if on_ready is not None and side is None:
+                on_ready(flat, lay.p_lo, lay.p_hi)
             if lay.li > 0:
                 # gradient wrt this block's input slice, written into gin at the slice's channel offset
                 self._timed('dgrad', lay, ops.conv_dgrad_raw, lay.geom, lay.dy, lay.cout_p, 0, lay.wd, lay.gin, lay.tin.ld,

@@ -213,7 +213,7 @@ class _DarknetFn(torch.autograd.Function):
             raise McamdError("backward through an eval-mode forward is not supported; call model.train()")
         if eng.serial != ctx.serial:
             raise McamdError("backward() must follow the forward() it belongs to (activations are kept in place)")
-        flat, views = eng.backward(gout)
+        flat, views = eng.backward(gout, on_ready=ctx.model._grad_ready_hook)
         ctx.model._last_flat_grad = flat
         hook = ctx.model._grad_hook
         if hook is not None:
@@ -247,6 +247,7 @@ class Darknet(nn.Module):
         self._engines = {}
         self._weights_dirty = True
         self._grad_hook = None          # callable(flat_grad) run at the end of backward (data parallel)
+        self._grad_ready_hook = None    # callable(flat_grad, lo, hi): that slice is final (overlapped all-reduce)
         self._last_flat_grad = None
         self.grad_scale = 256.0         # fp16 gradient scaling inside the engine, undone in fp32
 

@@ -172,6 +172,28 @@ def _dp_worker(rank, world, port, tmp):
     flat = torch.arange(2500, dtype=torch.float32) * (rank + 1)
     red.reduce_flat(flat)
     assert torch.allclose(flat, torch.arange(2500, dtype=torch.float32) * 1.5)
+    # overlapped path: slices reported from the tail (as the engine's backward does), buckets of >= 700
+    # elements, collectives of <= 1000; then the same reducer again (state must reset between steps)
+    red2 = dp.GradReducer(chunk_elems=1000, bucket_elems=700)
+    for step in range(2):
+        flat = torch.arange(2500, dtype=torch.float32) * (rank + 1) + step
+        n0 = red2.collectives
+        edges = [2500, 2400, 1500, 1490, 900, 300, 0]
+        for hi, lo in zip(edges[:-1], edges[1:]):
+            red2.ready(flat, lo, hi)
+        assert red2.collectives - n0 == 3          # [1500,2500) -> 1, [900,1500) not yet, [300,1500) -> 2 chunks
+        red2.finish(flat)
+        assert red2.collectives - n0 == 4
+        assert torch.allclose(flat, torch.arange(2500, dtype=torch.float32) * 1.5 + step)
+    flat = torch.ones(100) * (rank + 1)
+    red2.finish(flat)                               # nothing reported piecewise: one collective over everything
+    assert torch.allclose(flat, torch.full((100,), 1.5))
+    try:
+        red2.ready(flat, 50, 100)
+        red2.ready(flat, 0, 40)                     # gap: must be refused, not silently mis-reduced
+        raise AssertionError("non-contiguous slices accepted")
+    except RuntimeError:
+        red2._pending, red2._lo, red2._hi = [], None, None
     lin = torch.nn.Linear(4, 3)
     for p in lin.parameters():
         p.grad = torch.full_like(p, float(rank))
