@@ -117,8 +117,11 @@ int mcamd_conv_dgrad(const mcamd_conv_geom* g, const void* dy, int32_t dy_ld, in
 
 /* dW = wgrad(x, dy) * mask / grad_scale, written as fp32 OIHW -- autograd's weight gradient of
  * `self.weight * mask_var` followed by F.conv2d.  Deterministic (slab reduction, no atomics).
- * Filters whose mask row is entirely zero are skipped when `filter_keep` (device int32[cout],
- * 0 = skip) is given.  `dbias` (fp32[cout], may be NULL) receives sum over pixels of dy / grad_scale. */
+ * `filter_keep` is reserved and must be NULL or is ignored: fully pruned filters are skipped one level
+ * up -- the caller keeps the surviving filters first in its channel order and passes a geometry whose
+ * `cout` is the kept count (and the channel-gathered mask), so that forward, dgrad and wgrad all run on
+ * the kept filters only (modelcompression_amd/engine.py, "filter compaction").
+ * `dbias` (fp32[cout], may be NULL) receives sum over pixels of dy / grad_scale. */
 size_t mcamd_conv_wgrad_workspace_bytes(const mcamd_conv_geom* g);
 int mcamd_conv_wgrad(const mcamd_conv_geom* g, const void* x, const void* dy, int32_t dy_ld,
                      int32_t dy_choff, const float* mask_oihw, const int32_t* filter_keep,
@@ -133,10 +136,15 @@ int mcamd_conv_wgrad(const mcamd_conv_geom* g, const void* x, const void* dy, in
 /* Batch statistics from the conv epilogue's partial sums -> affine coefficients.
  * scale = gamma*invstd, shift = beta - mean*scale.  training != 0: batch stats (biased var),
  * running stats updated with the unbiased var; training == 0: running stats. */
+/* `chan_perm` (device int32[C], may be NULL = identity): statistics and the output vectors are in the
+ * kernels' physical channel order, gamma/beta/running_* in the module's order; physical channel c reads and
+ * updates index chan_perm[c] of them.  The engine keeps the filters that survive filter pruning first (its
+ * convolutions then run on the kept filters only) and passes that order here. */
 int mcamd_bn_coeffs(const float* stats, int32_t stats_rows, int32_t stats_ld, int32_t C, int64_t count,
                     const float* gamma, const float* beta, float* running_mean, float* running_var,
                     float momentum, float eps, int32_t training,
-                    float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
+                    float* scale, float* shift, float* save_mean, float* save_invstd,
+                    const int32_t* chan_perm, void* stream);
 
 #define MCAMD_DST_PLAIN 0  /* same resolution */
 #define MCAMD_DST_POOL 1   /* 2x2/2 max pool */
@@ -172,6 +180,8 @@ typedef struct mcamd_act_bwd_desc {
     const float* dy_keep;      /* optional fp32 [C]: 0 marks a fully pruned filter; its dY channel is written as
                                   zero (its weights are zero, so dgrad/wgrad never need it -- and a dead filter has
                                   zero batch variance, which would otherwise blow dY up by 1/sqrt(eps)) */
+    const int32_t* chan_perm;  /* optional device int32[C]: dgamma / dbeta of physical channel c are written to
+                                  index chan_perm[c] (see mcamd_bn_coeffs) */
 } mcamd_act_bwd_desc;
 size_t mcamd_bn_act_bwd_workspace_bytes(const mcamd_act_bwd_desc* d);
 int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, size_t workspace_bytes, void* stream);

@@ -45,7 +45,7 @@ class ActBwdDesc(C.Structure):
                 ("g2", C.c_void_p), ("g2_ld", C.c_int32), ("g2_choff", C.c_int32),
                 ("dy", C.c_void_p), ("dy_ld", C.c_int32), ("dy_choff", C.c_int32),
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("grad_scale", C.c_float),
-                ("dy_keep", C.c_void_p)]
+                ("dy_keep", C.c_void_p), ("chan_perm", C.c_void_p)]
 
 
 EPI_RAW_F16, EPI_NCHW_F32, EPI_PAD_F16 = 0, 1, 2
@@ -66,7 +66,7 @@ SIGNATURES = {
     "mcamd_conv_dgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _I32, _I32, _P, C.POINTER(ConvEpilogue), _P]),
     "mcamd_conv_wgrad_workspace_bytes": (_SZ, [C.POINTER(ConvGeom)]),
     "mcamd_conv_wgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _P, _I32, _I32, _P, _P, _F, _P, _P, _P, _SZ, _P]),
-    "mcamd_bn_coeffs": (C.c_int, [_P, _I32, _I32, _I32, _I64, _P, _P, _P, _P, _F, _F, _I32, _P, _P, _P, _P, _P]),
+    "mcamd_bn_coeffs": (C.c_int, [_P, _I32, _I32, _I32, _I64, _P, _P, _P, _P, _F, _F, _I32, _P, _P, _P, _P, _P, _P]),
     "mcamd_bn_act_fwd": (C.c_int, [C.POINTER(ActDesc), _P]),
     "mcamd_bn_act_bwd_workspace_bytes": (_SZ, [C.POINTER(ActBwdDesc)]),
     "mcamd_bn_act_bwd": (C.c_int, [C.POINTER(ActBwdDesc), _P, _SZ, _P]),

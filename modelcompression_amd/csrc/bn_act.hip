@@ -16,7 +16,7 @@ __global__ __launch_bounds__(1024) void bn_coeffs_kernel(const float* stats, int
                                                          const float* gamma, const float* beta, float* rmean,
                                                          float* rvar, float momentum, float eps, int training,
                                                          float* scale, float* shift, float* save_mean,
-                                                         float* save_invstd) {
+                                                         float* save_invstd, const int* perm) {
     __shared__ double red[2][32][33];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
@@ -31,6 +31,10 @@ __global__ __launch_bounds__(1024) void bn_coeffs_kernel(const float* stats, int
     red[1][ry][cx] = s2;
     __syncthreads();
     if (ry != 0 || c >= C) return;
+    // `perm` (optional): the statistics / coefficient vectors are in the kernels' PHYSICAL channel order
+    // (kept filters first, engine.py filter compaction); the module's parameter vectors are in the
+    // reference's order.  pc = this physical channel's index into gamma/beta/running_*.
+    const int pc = perm ? perm[c] : c;
     double mean, var;
     if (training) {
         s1 = s2 = 0.0;
@@ -42,16 +46,16 @@ __global__ __launch_bounds__(1024) void bn_coeffs_kernel(const float* stats, int
         var = s2 / count - mean * mean;  // biased variance (normalisation)
         if (var < 0.0) var = 0.0;
         double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + (double)momentum * mean);
-        rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + (double)momentum * unbiased);
+        rmean[pc] = (float)((1.0 - momentum) * (double)rmean[pc] + (double)momentum * mean);
+        rvar[pc] = (float)((1.0 - momentum) * (double)rvar[pc] + (double)momentum * unbiased);
     } else {
-        mean = rmean[c];
-        var = rvar[c];
+        mean = rmean[pc];
+        var = rvar[pc];
     }
     double invstd = 1.0 / sqrt(var + (double)eps);
-    float sc = (float)((double)gamma[c] * invstd);
+    float sc = (float)((double)gamma[pc] * invstd);
     scale[c] = sc;
-    shift[c] = (float)((double)beta[c] - mean * (double)sc);
+    shift[c] = (float)((double)beta[pc] - mean * (double)sc);
     if (save_mean) save_mean[c] = (float)mean;
     if (save_invstd) save_invstd[c] = (float)invstd;
 }
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(ActBwdArgs a) {
 
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* slab, int nblocks, int C, double count,
                                                                float inv_scale, float* dgamma, float* dbeta,
-                                                               float* coef) {
+                                                               float* coef, const int* perm) {
     __shared__ double red[2][32][33];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
@@ -351,8 +355,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* slab
         sb += red[0][k][cx];
         sg += red[1][k][cx];
     }
-    if (dbeta) dbeta[c] = (float)(sb * inv_scale);
-    if (dgamma) dgamma[c] = (float)(sg * inv_scale);
+    const int pc = perm ? perm[c] : c;   // parameter-order index of this physical channel
+    if (dbeta) dbeta[pc] = (float)(sb * inv_scale);
+    if (dgamma) dgamma[pc] = (float)(sg * inv_scale);
     coef[c] = (float)(sb / count);
     coef[C + c] = (float)(sg / count);
 }
@@ -404,12 +409,12 @@ static int stream_grid(long long items) {
 extern "C" int mcamd_bn_coeffs(const float* stats, int32_t stats_rows, int32_t stats_ld, int32_t C, int64_t count,
                                const float* gamma, const float* beta, float* running_mean, float* running_var,
                                float momentum, float eps, int32_t training, float* scale, float* shift,
-                               float* save_mean, float* save_invstd, void* stream) {
+                               float* save_mean, float* save_invstd, const int32_t* chan_perm, void* stream) {
     MCAMD_REQUIRE(C > 0 && gamma && beta && running_mean && running_var && scale && shift, "bn_coeffs: null argument");
     MCAMD_REQUIRE(!training || (stats && stats_rows > 0 && stats_ld >= C && count > 0), "bn_coeffs: bad statistics slab");
     hipLaunchKernelGGL(bn_coeffs_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, stats, stats_rows,
                        stats_ld, C, (double)count, gamma, beta, running_mean, running_var, momentum, eps, training,
-                       scale, shift, save_mean, save_invstd);
+                       scale, shift, save_mean, save_invstd, (const int*)chan_perm);
     MCAMD_LAUNCH_CHECK("bn_coeffs");
     return MCAMD_OK;
 }
@@ -515,7 +520,7 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
     BWD_LAUNCH(0)
     MCAMD_LAUNCH_CHECK("bn_act_bwd reduce");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + 31) / 32), dim3(1024), 0, st, (const float*)a.slab, grid, d->C,
-                       count, 1.0f / d->grad_scale, d->dgamma, d->dbeta, coef);
+                       count, 1.0f / d->grad_scale, d->dgamma, d->dbeta, coef, (const int*)d->chan_perm);
     MCAMD_LAUNCH_CHECK("bn_act_bwd finalize");
     BWD_LAUNCH(1)
     MCAMD_LAUNCH_CHECK("bn_act_bwd apply");

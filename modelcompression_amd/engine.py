@@ -114,6 +114,7 @@ class Engine:
                     assert (h, w) == (h2, w2)
                     shape[ind] = (c1 + c2, h, w)
 
+        self._bops, self._srcs, self._shape = bops, srcs, shape
         # fusion: what each conv's activation kernel produces
         conv_inds = [i for i, (t, _) in enumerate(bops) if t == "convolutional"]
         fused = {}
@@ -247,15 +248,21 @@ class Engine:
             lay.gin = None
             if lay.li > 0:
                 lay.gin = torch.empty(lay.M * lay.tin.ld, dtype=ops.HALF, device=dev)
+            lay.perm = lay.perm32 = lay.in_perm = lay.g_rows = lay.g_cols = lay.mask_phys = None
+            lay.n_act, lay.geom_act, lay.gather = lay.cout, lay.geom, False
             if not lay.is_last:
-                lay.y = torch.empty(lay.M * lay.cout, dtype=ops.HALF, device=dev)
-                lay.stats = torch.empty(ops.stats_rows(g), 2, ops.round_up(lay.cout, 256), **f32)
+                # zero-initialised: with filter compaction the convolution writes the kept channels only
+                lay.y = torch.zeros(lay.M * lay.cout, dtype=ops.HALF, device=dev)
+                lay.stats = torch.zeros(ops.stats_rows(g), 2, ops.round_up(lay.cout, 256), **f32)
                 lay.scale, lay.shift, lay.mean, lay.invstd = (torch.empty(lay.cout, **f32) for _ in range(4))
                 lay.out_t = place.get(lay.out_id)
                 lay.out2_t = place.get(lay.out2_id) if lay.out2_id is not None else None
                 if lay.out_t is None:
                     raise NotImplementedError("conv block %d output is never consumed" % lay.index)
         self.wgrad_ws = torch.empty(max(wbytes, 16), dtype=torch.uint8, device=dev)
+        self.dw_scratch = None            # weight gradient in physical channel order (compacted layers)
+        self._mask_keys = None
+        self.compact = os.environ.get("MCAMD_COMPACT", "1") == "1"
         maxc = max(l.cout for l in self.layers)
         self.bwd_ws = torch.empty(ops.bn_act_bwd_workspace_bytes(maxc), dtype=torch.uint8, device=dev)
         self.params = list(model.parameters())
@@ -312,19 +319,106 @@ class Engine:
         sig = self._signature()
         if not force and sig == self._packed_sig and not self.model._weights_dirty:
             return
+        mkeys = tuple(None if not lay.conv.mask_flag else (lay.conv.mask.data_ptr(), lay.conv.mask._version)
+                      for lay in self.layers)
+        if mkeys != self._mask_keys:         # masks are static during retraining: planned once
+            self._update_compaction()
+            self._mask_keys = mkeys
         for lay in self.layers:
             w = lay.conv.weight.data
             if w.dtype != torch.float32 or not w.is_contiguous():
                 raise McamdError("conv weights must be contiguous fp32 (master copy)")
-            mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
-            ops.pack_weights(lay.geom, w, mask, True, lay.wd is not None, lay.wp, lay.wd)
-            # filters whose mask is entirely zero: their dY is never needed (sparse-masked backward)
-            key = None if mask is None else (mask.data_ptr(), mask._version)
-            if key != lay.keep_key:          # masks are static during retraining: computed once
-                lay.keep = (mask.reshape(mask.shape[0], -1).amax(1) != 0).float() if mask is not None else None
-                lay.keep_key = key
+            if lay.gather:                   # physical channel order: kept filters first / permuted inputs
+                w = w[lay.g_rows[:, None], lay.g_cols[None, :]]
+                ops.pack_weights(lay.geom_act, w, lay.mask_phys, True, lay.wd is not None, lay.wp, lay.wd)
+            else:
+                mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
+                ops.pack_weights(lay.geom, w, mask, True, lay.wd is not None, lay.wp, lay.wd)
         self._packed_sig = sig
         self.model._weights_dirty = False
+
+    # ------------------------------------------------------------------ filter compaction
+    def _update_compaction(self):
+        """Sparse-masked path: skip the filters a filter mask removed (north_star: "a sparse-masked wgrad
+        path that skips zeroed filters"; the reference multiplies by the mask and computes them anyway,
+        layers.py:59-64).
+
+        A filter whose mask row is all zero has zero effective weights, so its raw conv output is exactly 0,
+        its weight gradient is 0 and it contributes nothing to the input gradient.  Per BN conv block the
+        engine therefore orders that block's output channels PHYSICALLY as [kept filters..., removed
+        filters...] and runs forward, dgrad and wgrad with cout = the kept count (rounded up to 8): the
+        removed channels of y / dY are never written and stay zero, BatchNorm then yields their constant
+        leaky(beta) exactly as in the dense computation.  Everything downstream that indexes channels by
+        position follows the permutation: the consumer's weights are gathered to the physical input order
+        before packing, its weight gradient is scattered back, and the BN parameter vectors are addressed
+        through `chan_perm`.  Pool / reorg / route keep or compose permutations.  Called when a mask
+        object changes (one host sync for the kept counts)."""
+        dev = self.device
+        tperm = {-1: None}               # tensor id -> LongTensor physical position -> original channel (None = identity)
+        by_ci = {lay.index: lay for lay in self.layers}
+        need_scratch, wbytes = 0, 16
+        for ind, (t, _) in enumerate(self._bops):
+            src = self._srcs[ind]
+            if t == "convolutional":
+                lay = by_ci[ind]
+                mask = lay.conv.mask if lay.conv.mask_flag else None
+                if mask is not None and (not mask.is_cuda or mask.dtype != torch.float32 or tuple(mask.shape) != tuple(lay.conv.weight.shape)):
+                    raise McamdError("conv block %d: mask must be a CUDA fp32 tensor shaped like the weight" % ind)
+                perm, n_act, keep = None, lay.cout, None
+                if mask is not None:
+                    alive = mask.reshape(lay.cout, -1).amax(1) != 0
+                    keep = alive.float()
+                    if self.compact and lay.bn is not None:
+                        n8 = min(lay.cout, ops.round_up(max(int(alive.sum()), 1), 8))
+                        if n8 < lay.cout:
+                            perm = torch.cat((torch.nonzero(alive).flatten(), torch.nonzero(~alive).flatten()))
+                            n_act = n8
+                in_perm = tperm[src[0]]
+                lay.perm, lay.n_act, lay.in_perm = perm, n_act, in_perm
+                lay.perm32 = perm.to(torch.int32).contiguous() if perm is not None else None
+                lay.keep = None if keep is None else (keep[perm].contiguous() if perm is not None else keep)
+                lay.geom_act = lay.geom if perm is None else ops.geom(self.B, lay.H, lay.W, lay.k, lay.cin, n_act,
+                                                                      lay.tin.ld, lay.tin.choff, lay.stem)
+                lay.gather = perm is not None or in_perm is not None
+                lay.g_rows = lay.g_cols = lay.mask_phys = None
+                if lay.gather:
+                    lay.g_rows = perm[:n_act] if perm is not None else torch.arange(lay.cout, device=dev)
+                    lay.g_cols = in_perm if in_perm is not None else torch.arange(lay.cin, device=dev)
+                    if mask is not None:
+                        lay.mask_phys = mask[lay.g_rows[:, None], lay.g_cols[None, :]].contiguous()
+                    need_scratch = max(need_scratch, n_act * lay.cin * lay.k * lay.k)
+                if lay.bn is not None:
+                    rows = ops.stats_rows(lay.geom_act)
+                    if lay.stats.shape[0] != rows:
+                        lay.stats = torch.zeros(rows, 2, lay.stats.shape[2], dtype=torch.float32, device=dev)
+                    else:
+                        lay.stats.zero_()
+                    lay.y.zero_()
+                wbytes = max(wbytes, ops.wgrad_workspace_bytes(lay.geom_act))
+                tperm[ind] = perm
+            elif t == "maxpool":
+                tperm[ind] = tperm[src[0]]
+            elif t == "reorg":
+                p = tperm[src[0]]
+                C = self._shape[src[0]][0]
+                tperm[ind] = None if p is None else torch.cat([p + q * C for q in range(4)])
+            elif t == "route" and len(src) == 2:
+                pa, pb = tperm[src[0]], tperm[src[1]]
+                ca, cb = self._shape[src[0]][0], self._shape[src[1]][0]
+                if pa is None and pb is None:
+                    tperm[ind] = None
+                else:
+                    pa = pa if pa is not None else torch.arange(ca, device=dev)
+                    pb = pb if pb is not None else torch.arange(cb, device=dev)
+                    tperm[ind] = torch.cat((pa, pb + ca))
+            elif t == "route":
+                tperm[ind] = tperm[src[0]]
+            else:
+                tperm[ind] = None
+        if need_scratch and (self.dw_scratch is None or self.dw_scratch.numel() < need_scratch):
+            self.dw_scratch = torch.empty(need_scratch, dtype=torch.float32, device=dev)
+        if wbytes > self.wgrad_ws.numel():
+            self.wgrad_ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, training):
@@ -347,15 +441,15 @@ class Engine:
             xin = self.bufs[lay.tin.buf]
             if lay.is_last:
                 bias = lay.conv.bias.data if lay.conv.bias is not None else None
-                self._timed('fwd', lay, ops.conv_fwd_nchw, lay.geom, xin, lay.wp, out, bias)
+                self._timed('fwd', lay, ops.conv_fwd_nchw, lay.geom_act, xin, lay.wp, out, bias)
                 if lay.border_map is not None:
                     out += lay.border_map
                 continue
             bn = lay.bn
-            self._timed('fwd', lay, ops.conv_fwd_raw, lay.geom, xin, lay.wp, lay.y, lay.cout, 0, lay.stats if training else None)
+            self._timed('fwd', lay, ops.conv_fwd_raw, lay.geom_act, xin, lay.wp, lay.y, lay.cout, 0, lay.stats if training else None)
             ops.bn_coeffs(lay.stats if training else None, lay.cout, lay.M, bn.weight.data, bn.bias.data,
                           bn.running_mean, bn.running_var, training, lay.scale, lay.shift, lay.mean, lay.invstd,
-                          momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps)
+                          momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps, perm=lay.perm32)
             t, t2 = lay.out_t, lay.out2_t
             ops.bn_act_fwd(B, lay.H, lay.W, lay.cout, lay.y, lay.cout, 0, lay.scale, lay.shift, lay.slope, lay.mode,
                            self.bufs[t.buf], t.ld, t.choff,
@@ -398,10 +492,20 @@ class Engine:
                 ops.bn_act_bwd(self.B, lay.H, lay.W, lay.cout, lay.y, lay.cout, 0, lay.scale, lay.shift, lay.mean,
                                lay.invstd, lay.slope, lay.mode, cons.gin, cons.tin.ld, t.choff, lay.dy, lay.cout_p, 0,
                                gmap[id(lay.bn.weight)], gmap[id(lay.bn.bias)], S, g2, g2_ld or 0, g2_choff or 0,
-                               self.bwd_ws, lay.keep)
+                               self.bwd_ws, lay.keep, lay.perm32)
             mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
             dbias = gmap[id(lay.conv.bias)] if lay.conv.bias is not None else None
-            if side is None:
+            if lay.gather:
+                # kept filters only, in physical channel order; scattered back to OIHW order (rows of removed
+                # filters are zero, as `grad * mask` makes them in the reference)
+                dwt = self.dw_scratch[:lay.n_act * lay.cin * lay.k * lay.k].view(lay.n_act, lay.cin, lay.k, lay.k)
+                self._timed('wgrad', lay, ops.conv_wgrad, lay.geom_act, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
+                            dwt, lay.mask_phys, S, dbias, self.wgrad_ws)
+                gw = gmap[id(lay.conv.weight)]
+                if lay.perm is not None:
+                    gw.zero_()
+                gw[lay.g_rows[:, None], lay.g_cols[None, :]] = dwt
+            elif side is None:
                 self._timed('wgrad', lay, ops.conv_wgrad, lay.geom, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
                             gmap[id(lay.conv.weight)], mask, S, dbias, self.wgrad_ws)
             else:
@@ -417,7 +521,7 @@ class Engine:
                 on_ready(flat, lay.p_lo, lay.p_hi)
             if lay.li > 0:
                 # gradient wrt this block's input slice, written into gin at the slice's channel offset
-                self._timed('dgrad', lay, ops.conv_dgrad_raw, lay.geom, lay.dy, lay.cout_p, 0, lay.wd, lay.gin, lay.tin.ld,
+                self._timed('dgrad', lay, ops.conv_dgrad_raw, lay.geom_act, lay.dy, lay.cout_p, 0, lay.wd, lay.gin, lay.tin.ld,
                             lay.tin.choff)
         if side is not None:
             main.wait_stream(side)

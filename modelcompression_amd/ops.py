@@ -133,13 +133,22 @@ def conv_wgrad(g, x, dy, dy_ld, dy_choff, dw, mask=None, grad_scale=1.0, dbias=N
                                    ptr(dbias), ptr(workspace), workspace.numel(), stream_ptr()), "mcamd_conv_wgrad")
 
 
+def _perm_ptr(perm, C_):
+    if perm is None:
+        return None
+    if perm.dtype != torch.int32 or perm.numel() != C_ or not perm.is_contiguous() or not perm.is_cuda:
+        raise L.McamdError("channel permutation must be a contiguous CUDA int32 vector of %d entries" % C_)
+    return perm.data_ptr()
+
+
 def bn_coeffs(stats, C_, count, gamma, beta, rmean, rvar, training, scale, shift, mean=None, invstd=None,
-              momentum=0.1, eps=1e-5):
+              momentum=0.1, eps=1e-5, perm=None):
+    """`perm` (int32 [C], optional): physical channel c uses gamma/beta/running_*[perm[c]]."""
     rows = stats.shape[0] if stats is not None else 0
     ld = stats.shape[2] if stats is not None else 0
     check(L.lib().mcamd_bn_coeffs(ptr(stats), rows, ld, C_, count, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
                                   momentum, eps, 1 if training else 0, ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
-                                  stream_ptr()), "mcamd_bn_coeffs")
+                                  _perm_ptr(perm, C_), stream_ptr()), "mcamd_bn_coeffs")
 
 
 def bn_act_fwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, slope, mode, dst, dst_ld, dst_choff=0, dst2=None,
@@ -160,7 +169,8 @@ def bn_act_fwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, slope, mode, dst, ds
 
 
 def bn_act_bwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, mean, invstd, slope, mode, g, g_ld, g_choff, dy, dy_ld,
-               dy_choff, dgamma, dbeta, grad_scale=1.0, g2=None, g2_ld=0, g2_choff=0, workspace=None, dy_keep=None):
+               dy_choff, dgamma, dbeta, grad_scale=1.0, g2=None, g2_ld=0, g2_choff=0, workspace=None, dy_keep=None,
+               perm=None):
     d = ActBwdDesc()
     d.B, d.H, d.W, d.C = B, H, W, C_
     d.y, d.y_ld, d.y_choff = y.data_ptr(), y_ld, y_choff
@@ -174,6 +184,7 @@ def bn_act_bwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, mean, invstd, slope,
     d.dbeta = dbeta.data_ptr() if dbeta is not None else None
     d.grad_scale = grad_scale
     d.dy_keep = dy_keep.data_ptr() if dy_keep is not None else None
+    d.chan_perm = _perm_ptr(perm, C_)
     need = int(L.lib().mcamd_bn_act_bwd_workspace_bytes(C.byref(d)))
     if workspace is None:
         workspace = torch.empty(need, dtype=torch.uint8, device=y.device)
