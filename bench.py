@@ -53,6 +53,38 @@ def cpu_baseline(batch, steps):
             "sample": "B=%d fwd+bwd+SGD x%d steps of the same YOLOv2-VOC 416x416 workload (oracle, fp32 oneDNN)" % (batch, steps)}
 
 
+def bench_slim(args, model, dev, rank):
+    """BASELINE configs[4]: eval forward of the physically slim model next to the masked-dense one."""
+    import tempfile
+    from modelcompression_amd import slim
+    from modelcompression_amd.synthetic import synthetic_batch
+    B = args.batch
+    with tempfile.TemporaryDirectory() as tmp:
+        thin = slim.slim_export(model, os.path.join(tmp, "slim.cfg"))
+    rows = slim.slim_summary(model, thin)
+    x = synthetic_batch(B, 416, 416, seed=rank, device=dev)
+    model.eval()
+    res = {}
+    with torch.no_grad():
+        for name, net in (("masked_dense", model), ("slim", thin)):
+            for _ in range(args.warmup):
+                net(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                net(x)
+            torch.cuda.synchronize()
+            res[name] = (time.perf_counter() - t0) / args.steps
+    if rank == 0:
+        print(json.dumps({
+            "metric": "images/sec (inference forward, 416x416)", "value": round(B / res["slim"], 1), "unit": "images/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(res["slim"] * 1e3, 3),
+            "higher_is_better": True, "dtype": "fp16", "data": "synthetic",
+            "config": {"workload": "YOLOv2-VOC filter-pruned 60 %% physically slim eval forward, B=%d (BASELINE configs[4])" % B,
+                       "filters_kept": sum(r[2] for r in rows), "filters_dense": sum(r[1] for r in rows),
+                       "masked_dense_images_per_s": round(B / res["masked_dense"], 1)}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,6 +94,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--layer-table", default="", help="write the per-launch timing table to this file")
+    ap.add_argument("--workload", default="dense", choices=["dense", "filter40", "weight80", "slim60"],
+                    help="dense = BASELINE configs[1] (the default bench line); filter40 / weight80 = the retrain step of "
+                         "configs[2] / configs[3] with the reference's masks; slim60 = configs[4], eval forward of the "
+                         "physically slim 60 %% filter-pruned model (use --batch 128)")
     args = ap.parse_args()
 
     from modelcompression_amd import nets, dp, YOLOV2_VOC_CFG, ops
@@ -81,6 +117,19 @@ def main():
     init_synthetic(model, seed=0)
     model.to(dev).train()
     B = args.batch
+    wl_name = "dense (0% prune)"
+    if args.workload != "dense":
+        from modelcompression_amd.pruning.weightPruning.methods import weight_prune, quick_filter_prune
+        if args.workload == "weight80":
+            masks, wl_name = weight_prune(model, 80.0), "weight-pruned 80 % (magnitude masks)"
+        else:
+            perc = 40.0 if args.workload == "filter40" else 60.0
+            masks, wl_name = quick_filter_prune(model, perc), "filter-pruned %g %% (kept filters only)" % perc
+        if world > 1:
+            dp.broadcast_masks(masks, src=0)
+        model.set_masks(masks)
+    if args.workload == "slim60":
+        return bench_slim(args, model, dev, rank)
     opt = torch.optim.SGD(model.parameters(), lr=1e-5, momentum=0.9, dampening=0, weight_decay=0.0005 * B)
     reducer = dp.attach(model) if world > 1 else None
     x = synthetic_batch(B, 416, 416, seed=rank, device=dev)   # resident in HBM before the timed region
@@ -177,7 +226,8 @@ def main():
         "metric": "images/sec (fwd+bwd, 416x416)", "value": round(value, 2), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
-        "config": {"workload": "YOLOv2-VOC dense (0%% prune) fwd+bwd+SGD step, B=%d per GPU, 416x416 (BASELINE configs[1])" % B,
+        "config": {"workload": "YOLOv2-VOC %s fwd+bwd+SGD step, B=%d per GPU, 416x416 (BASELINE configs[%d])" % (
+                       wl_name, B, {"dense": 1, "filter40": 2, "weight80": 3}[args.workload]),
                    "global_batch": world * B, "input": "3x416x416", "parallelism": "dp%d" % world,
                    "conv_tflops_whole_step": round(value * FWD_BWD_GFLOP_PER_IMG / 1e3, 1),
                    "frac_of_fp16_mfma_peak_whole_step": round(value * FWD_BWD_GFLOP_PER_IMG / 1e3 / (PEAK_FP16_TFLOPS * world), 4)},

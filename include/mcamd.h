@@ -96,14 +96,23 @@ int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int32_t out[4]
 int64_t mcamd_packed_elems_fwd(const mcamd_conv_geom* g);
 int64_t mcamd_packed_elems_dgrad(const mcamd_conv_geom* g);
 
+/* Physical channel order of one convolution (NULL pointers = identity).  With filter pruning the engine keeps
+ * the surviving filters first and computes only those: `g->cout` / `g->cin` then describe the PHYSICAL problem
+ * and the weight / mask / gradient tensors keep the module's OIHW order with `g->cin` input channels per filter:
+ * physical filter n is tensor row rows[n], physical input channel c is tensor column cols[c]. */
+typedef struct mcamd_chan_map {
+    const int32_t* rows;   /* device int32[g->cout] or NULL */
+    const int32_t* cols;   /* device int32[g->cin] or NULL */
+} mcamd_chan_map;
+
 /* OIHW fp32 master (optionally * mask) -> fp16 kernel layouts.  Replaces the per-forward
  * `self.weight * mask_var` of layers.py:59 (done once per optimizer step here).
  *   fwd  : [Npad][t*cin + c]  = w[n][c][ty][tx],  t = ty*k + tx;  Npad = roundup(cout,256); pad rows zero
  *          (stem: [Npad][ty*32 + tx*4 + c], other slots zero)
  *   dgrad: [Cpad][t*cout_p + n] = w[n][c][k-1-ty][k-1-tx]; cout_p = roundup(cout,32); Cpad = roundup(cin,256)
- * Either destination may be NULL. */
+ * Either destination may be NULL.  `map` (may be NULL): gather rows / columns of w and mask, see mcamd_chan_map. */
 int mcamd_pack_weights(const mcamd_conv_geom* g, const float* w_oihw, const float* mask_oihw,
-                       void* wp_fwd, void* wp_dgrad, void* stream);
+                       const mcamd_chan_map* map, void* wp_fwd, void* wp_dgrad, void* stream);
 
 /* y = conv(x, w) -- replaces F.conv2d at layers.py:60-64. */
 int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const void* wp_fwd,
@@ -117,14 +126,15 @@ int mcamd_conv_dgrad(const mcamd_conv_geom* g, const void* dy, int32_t dy_ld, in
 
 /* dW = wgrad(x, dy) * mask / grad_scale, written as fp32 OIHW -- autograd's weight gradient of
  * `self.weight * mask_var` followed by F.conv2d.  Deterministic (slab reduction, no atomics).
- * `filter_keep` is reserved and must be NULL or is ignored: fully pruned filters are skipped one level
- * up -- the caller keeps the surviving filters first in its channel order and passes a geometry whose
- * `cout` is the kept count (and the channel-gathered mask), so that forward, dgrad and wgrad all run on
- * the kept filters only (modelcompression_amd/engine.py, "filter compaction").
+ * Fully pruned filters are skipped through `map` (may be NULL): the caller keeps the surviving filters first
+ * in its channel order and passes a geometry whose `cout` is the kept count, so that forward, dgrad and
+ * wgrad all run on the kept filters only (modelcompression_amd/engine.py, "filter compaction").  With a map,
+ * dW[rows[n]][cols[c]] receives the gradient of physical (n, c) (the mask is read at the same place) and
+ * tensor rows that are not in rows[] are NOT written: the caller zeroes dw_oihw first.
  * `dbias` (fp32[cout], may be NULL) receives sum over pixels of dy / grad_scale. */
 size_t mcamd_conv_wgrad_workspace_bytes(const mcamd_conv_geom* g);
 int mcamd_conv_wgrad(const mcamd_conv_geom* g, const void* x, const void* dy, int32_t dy_ld,
-                     int32_t dy_choff, const float* mask_oihw, const int32_t* filter_keep,
+                     int32_t dy_choff, const float* mask_oihw, const mcamd_chan_map* map,
                      float grad_scale, float* dw_oihw, float* dbias, void* workspace,
                      size_t workspace_bytes, void* stream);
 

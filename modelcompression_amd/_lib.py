@@ -36,6 +36,10 @@ class ActDesc(C.Structure):
                 ("border", C.c_void_p)]
 
 
+class ChanMap(C.Structure):
+    _fields_ = [("rows", C.c_void_p), ("cols", C.c_void_p)]
+
+
 class ActBwdDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
                 ("y", C.c_void_p), ("y_ld", C.c_int32), ("y_choff", C.c_int32),
@@ -61,11 +65,11 @@ SIGNATURES = {
     "mcamd_conv_tile_info": (C.c_int, [C.POINTER(ConvGeom), _I32, C.POINTER(_I32)]),
     "mcamd_packed_elems_fwd": (_I64, [C.POINTER(ConvGeom)]),
     "mcamd_packed_elems_dgrad": (_I64, [C.POINTER(ConvGeom)]),
-    "mcamd_pack_weights": (C.c_int, [C.POINTER(ConvGeom), _P, _P, _P, _P, _P]),
+    "mcamd_pack_weights": (C.c_int, [C.POINTER(ConvGeom), _P, _P, C.POINTER(ChanMap), _P, _P, _P]),
     "mcamd_conv_fwd": (C.c_int, [C.POINTER(ConvGeom), _P, _P, C.POINTER(ConvEpilogue), _P]),
     "mcamd_conv_dgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _I32, _I32, _P, C.POINTER(ConvEpilogue), _P]),
     "mcamd_conv_wgrad_workspace_bytes": (_SZ, [C.POINTER(ConvGeom)]),
-    "mcamd_conv_wgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _P, _I32, _I32, _P, _P, _F, _P, _P, _P, _SZ, _P]),
+    "mcamd_conv_wgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _P, _I32, _I32, _P, C.POINTER(ChanMap), _F, _P, _P, _P, _SZ, _P]),
     "mcamd_bn_coeffs": (C.c_int, [_P, _I32, _I32, _I32, _I64, _P, _P, _P, _P, _F, _F, _I32, _P, _P, _P, _P, _P, _P]),
     "mcamd_bn_act_fwd": (C.c_int, [C.POINTER(ActDesc), _P]),
     "mcamd_bn_act_bwd_workspace_bytes": (_SZ, [C.POINTER(ActBwdDesc)]),

@@ -67,7 +67,8 @@ extern "C" int64_t mcamd_packed_elems_dgrad(const mcamd_conv_geom* g) {
 // weight packing
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_fwd_kernel(const float* w, const float* mask, half_t* wp, int Cout, int Cin,
-                                                       int ks, int cin_tap, int stem, long long total, int ktot) {
+                                                       int ks, int cin_tap, int stem, long long total, int ktot,
+                                                       const int* rmap, const int* cmap) {
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         int n = (int)(idx / ktot);
         int k = (int)(idx - (long long)n * ktot);
@@ -89,7 +90,8 @@ __global__ __launch_bounds__(256) void pack_fwd_kernel(const float* w, const flo
                 ok = c < Cin;
             }
             if (ok) {
-                long long src = (((long long)n * Cin + c) * ks + ty) * ks + tx;
+                const int ns = rmap ? rmap[n] : n, cs = cmap ? cmap[c] : c;
+                long long src = (((long long)ns * Cin + cs) * ks + ty) * ks + tx;
                 v = w[src];
                 if (mask) v *= mask[src];
             }
@@ -99,7 +101,8 @@ __global__ __launch_bounds__(256) void pack_fwd_kernel(const float* w, const flo
 }
 
 __global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* w, const float* mask, half_t* wp, int Cout, int Cin,
-                                                         int ks, int cout_p, long long total, int ktot) {
+                                                         int ks, int cout_p, long long total, int ktot,
+                                                         const int* rmap, const int* cmap) {
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         int c = (int)(idx / ktot);
         int k = (int)(idx - (long long)c * ktot);
@@ -108,7 +111,8 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* w, const f
         float v = 0.f;
         if (c < Cin && n < Cout) {
             int ty = t / ks, tx = t - ty * ks;
-            long long src = (((long long)n * Cin + c) * ks + (ks - 1 - ty)) * ks + (ks - 1 - tx);
+            const int ns = rmap ? rmap[n] : n, cs = cmap ? cmap[c] : c;
+            long long src = (((long long)ns * Cin + cs) * ks + (ks - 1 - ty)) * ks + (ks - 1 - tx);
             v = w[src];
             if (mask) v *= mask[src];
         }
@@ -116,10 +120,13 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* w, const f
     }
 }
 
-extern "C" int mcamd_pack_weights(const mcamd_conv_geom* g, const float* w_oihw, const float* mask_oihw, void* wp_fwd,
-                                  void* wp_dgrad, void* stream) {
+extern "C" int mcamd_pack_weights(const mcamd_conv_geom* g, const float* w_oihw, const float* mask_oihw,
+                                  const mcamd_chan_map* map, void* wp_fwd, void* wp_dgrad, void* stream) {
     if (check_geom(g, "pack_weights")) return MCAMD_EINVAL;
     MCAMD_REQUIRE(w_oihw, "pack_weights: null weights");
+    const int* rmap = map ? (const int*)map->rows : nullptr;
+    const int* cmap = map ? (const int*)map->cols : nullptr;
+    MCAMD_REQUIRE(!(g->stem && cmap), "pack_weights: the stem layer takes no input-channel map");
     hipStream_t st = (hipStream_t)stream;
     if (wp_fwd) {
         int ktot = ntaps_of(g) * cin_tap_of(g);
@@ -127,7 +134,7 @@ extern "C" int mcamd_pack_weights(const mcamd_conv_geom* g, const float* w_oihw,
         long long grid = (total + 256 * 4 - 1) / (256 * 4);
         if (grid > 4096) grid = 4096;
         hipLaunchKernelGGL(pack_fwd_kernel, dim3((int)grid), dim3(256), 0, st, w_oihw, mask_oihw, (half_t*)wp_fwd, g->cout,
-                           g->cin, g->ksize, cin_tap_of(g), g->stem, total, ktot);
+                           g->cin, g->ksize, cin_tap_of(g), g->stem, total, ktot, rmap, cmap);
     }
     if (wp_dgrad) {
         MCAMD_REQUIRE(!g->stem, "pack_weights: the stem layer has no dgrad packing");
@@ -136,7 +143,7 @@ extern "C" int mcamd_pack_weights(const mcamd_conv_geom* g, const float* w_oihw,
         long long grid = (total + 256 * 4 - 1) / (256 * 4);
         if (grid > 4096) grid = 4096;
         hipLaunchKernelGGL(pack_dgrad_kernel, dim3((int)grid), dim3(256), 0, st, w_oihw, mask_oihw, (half_t*)wp_dgrad,
-                           g->cout, g->cin, g->ksize, cout_p_of(g), total, ktot);
+                           g->cout, g->cin, g->ksize, cout_p_of(g), total, ktot, rmap, cmap);
     }
     MCAMD_LAUNCH_CHECK("pack_weights");
     return MCAMD_OK;
@@ -299,12 +306,14 @@ extern "C" size_t mcamd_conv_wgrad_workspace_bytes(const mcamd_conv_geom* g) {
 }
 
 extern "C" int mcamd_conv_wgrad(const mcamd_conv_geom* g, const void* x, const void* dy, int32_t dy_ld, int32_t dy_choff,
-                                const float* mask_oihw, const int32_t* filter_keep, float grad_scale, float* dw_oihw,
+                                const float* mask_oihw, const mcamd_chan_map* map, float grad_scale, float* dw_oihw,
                                 float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
     if (check_geom(g, "conv_wgrad")) return MCAMD_EINVAL;
     MCAMD_REQUIRE(x && dy && dw_oihw && workspace, "conv_wgrad: null argument");
     MCAMD_REQUIRE(grad_scale > 0.f, "conv_wgrad: grad_scale must be positive");
-    (void)filter_keep;  // reserved: zero filters are already exact through the mask multiply
+    const int* rmap = map ? (const int*)map->rows : nullptr;
+    const int* cmap = map ? (const int*)map->cols : nullptr;
+    MCAMD_REQUIRE(!(g->stem && cmap), "conv_wgrad: the stem layer takes no input-channel map");
     const int cin_tap = cin_tap_of(g), ntaps = ntaps_of(g);
     const long long M = (long long)g->B * g->H * g->W;
     WgradPlan p = wgrad_plan_for(g);
@@ -339,7 +348,7 @@ extern "C" int mcamd_conv_wgrad(const mcamd_conv_geom* g, const void* x, const v
                     : mcamd_wgrad_launch(a, p, st);
     if (rc) return rc;
     rc = mcamd_wgrad_finish_launch((const float*)workspace, p, a.ktot, cin_tap, g->stem, g->cout, g->cin, g->ksize,
-                                   mask_oihw, 1.0f / grad_scale, dw_oihw, st);
+                                   mask_oihw, 1.0f / grad_scale, dw_oihw, rmap, cmap, st);
     if (rc) return rc;
     if (dbias) {
         long long rows = (long long)g->B * (g->H + 2) * (g->W + 2);

@@ -376,7 +376,8 @@ __global__ __launch_bounds__(256, 2) void wgrad9_kernel(Wgrad9Args a) {
 template <int KK, int SG>
 __global__ __launch_bounds__(256) void wgrad_finish_vec_kernel(const float* slab, int nsplit, int rows_pad, int ktot,
                                                                int cin_tap, int Cout, int Cin, const float* mask,
-                                                               float inv_scale, float* dw) {
+                                                               float inv_scale, float* dw, const int* rmap,
+                                                               const int* cmap) {
     constexpr int OPB = 256 / SG;  // items per block
     __shared__ f32x4_t red[SG > 1 ? SG * OPB * KK : 1];
     const int c4n = Cin >> 2;
@@ -415,7 +416,17 @@ __global__ __launch_bounds__(256) void wgrad_finish_vec_kernel(const float* slab
     for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
         for (int t = 0; t < KK; ++t) out[jj * KK + t] = acc[t][jj] * inv_scale;
-    const long long base = ((long long)n * Cin + c) * KK;   // multiple of 4 floats: 16-byte aligned
+    if (cmap) {   // physical (n, c) -> tensor row rmap[n], column cmap[c]: four separate runs of KK floats
+        const long long row = rmap ? rmap[n] : n;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const long long b = (row * Cin + (cmap ? cmap[c + jj] : c + jj)) * KK;
+#pragma unroll
+            for (int t = 0; t < KK; ++t) dw[b + t] = mask ? out[jj * KK + t] * mask[b + t] : out[jj * KK + t];
+        }
+        return;
+    }
+    const long long base = ((long long)(rmap ? rmap[n] : n) * Cin + c) * KK;   // multiple of 4 floats: 16-byte aligned
 #pragma unroll
     for (int e = 0; e < KK; ++e) {
         f32x4_t ov = {out[4 * e], out[4 * e + 1], out[4 * e + 2], out[4 * e + 3]};
@@ -424,11 +435,40 @@ __global__ __launch_bounds__(256) void wgrad_finish_vec_kernel(const float* slab
     }
 }
 
+// Column-mapped form for the layers with few splits and big weight tensors: one workgroup per physical
+// filter row sums the slabs with coalesced float4 reads, scatters the row into LDS at its destination
+// (tensor) column order, then writes the whole OIHW row (x mask) with coalesced float4 stores.
+template <int KK>
+__global__ __launch_bounds__(256) void wgrad_finish_row_kernel(const float* slab, int nsplit, int rows_pad, int ktot,
+                                                               int cin_tap, int Cin, const float* mask, float inv_scale,
+                                                               float* dw, const int* rmap, const int* cmap) {
+    extern __shared__ __attribute__((aligned(16))) float rowbuf[];   // [Cin][KK] in tensor column order
+    const int n = blockIdx.x;
+    const int c4n = Cin >> 2;
+    const long long split_stride = (long long)rows_pad * ktot;
+    for (int i = threadIdx.x; i < KK * c4n; i += 256) {
+        const int t = i / c4n, c = (i - t * c4n) * 4;
+        const float* p = slab + (long long)n * ktot + t * cin_tap + c;
+        f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+        for (int s2 = 0; s2 < nsplit; ++s2) v += *(const f32x4_t*)(p + s2 * split_stride);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) rowbuf[(cmap ? cmap[c + jj] : c + jj) * KK + t] = v[jj] * inv_scale;
+    }
+    __syncthreads();
+    const long long base = (long long)(rmap ? rmap[n] : n) * Cin * KK;   // Cin % 4 == 0: 16-byte aligned
+    for (int i = threadIdx.x * 4; i < Cin * KK; i += 1024) {
+        f32x4_t v = *(const f32x4_t*)(rowbuf + i);
+        if (mask) v *= *(const f32x4_t*)(mask + base + i);
+        *(f32x4_t*)(dw + base + i) = v;
+    }
+}
+
 // Scalar form for any Cin (stem: Cin = 3): an item = one OIHW element.
 template <int SG>
 __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* slab, int nsplit, int rows_pad, int ktot,
                                                            int cin_tap, int stem, int Cout, int Cin, int KK,
-                                                           const float* mask, float inv_scale, float* dw) {
+                                                           const float* mask, float inv_scale, float* dw,
+                                                           const int* rmap, const int* cmap) {
     constexpr int OPB = 256 / SG;
     __shared__ float red[SG * OPB];
     const long long total = (long long)Cout * Cin * KK;
@@ -449,8 +489,15 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* slab, in
     if (sg != 0 || e >= total) return;
     for (int g = 1; g < SG; ++g) v += red[g * OPB + o];
     v *= inv_scale;
-    if (mask) v *= mask[e];
-    dw[e] = v;
+    long long dst = e;
+    if (rmap || cmap) {
+        const int n = (int)(e / (Cin * KK));
+        const int r = (int)(e - (long long)n * Cin * KK);
+        const int c = r / KK, t = r - c * KK;
+        dst = ((long long)(rmap ? rmap[n] : n) * Cin + (cmap ? cmap[c] : c)) * KK + t;
+    }
+    if (mask) v *= mask[dst];
+    dw[dst] = v;
 }
 
 // dbias[n] = sum over every padded pixel of dy[pixel][choff + n] / grad_scale (halo rows are zero).
@@ -662,10 +709,11 @@ int mcamd_wgrad_launch(WgradArgs& a, const WgradPlan& p, hipStream_t st) {
 
 template <int KK>
 static void launch_finish_vec(int sg, long long total, const float* slab, const WgradPlan& p, int ktot, int cin_tap, int Cout,
-                              int Cin, const float* mask, float inv_scale, float* dw, hipStream_t st) {
+                              int Cin, const float* mask, float inv_scale, float* dw, const int* rmap, const int* cmap,
+                              hipStream_t st) {
 #define F_CASE(SG_)                                                                                               \
     hipLaunchKernelGGL((wgrad_finish_vec_kernel<KK, SG_>), dim3((unsigned)((total + 256 / SG_ - 1) / (256 / SG_))), \
-                       dim3(256), 0, st, slab, p.nsplit, p.rows_pad, ktot, cin_tap, Cout, Cin, mask, inv_scale, dw)
+                       dim3(256), 0, st, slab, p.nsplit, p.rows_pad, ktot, cin_tap, Cout, Cin, mask, inv_scale, dw, rmap, cmap)
     if (sg == 1) F_CASE(1);
     else if (sg == 8) F_CASE(8);
     else F_CASE(32);
@@ -673,17 +721,27 @@ static void launch_finish_vec(int sg, long long total, const float* slab, const 
 }
 
 int mcamd_wgrad_finish_launch(const float* slab, const WgradPlan& p, int ktot, int cin_tap, int stem, int Cout, int Cin,
-                              int ksize, const float* mask, float inv_scale, float* dw, hipStream_t st) {
+                              int ksize, const float* mask, float inv_scale, float* dw, const int* rmap, const int* cmap,
+                              hipStream_t st) {
     const int sg = p.nsplit <= 4 ? 1 : (p.nsplit <= 64 ? 8 : 32);
-    if (!stem && Cin % 4 == 0 && (ksize == 1 || ksize == 3)) {
+    if (cmap && !stem && Cin % 4 == 0 && (ksize == 1 || ksize == 3) && p.nsplit <= 16 &&
+        (size_t)Cin * ksize * ksize * sizeof(float) <= 60 * 1024) {
+        const size_t lds = (size_t)Cin * ksize * ksize * sizeof(float);
+        if (ksize == 3)
+            hipLaunchKernelGGL(wgrad_finish_row_kernel<9>, dim3(Cout), dim3(256), lds, st, slab, p.nsplit, p.rows_pad, ktot,
+                               cin_tap, Cin, mask, inv_scale, dw, rmap, cmap);
+        else
+            hipLaunchKernelGGL(wgrad_finish_row_kernel<1>, dim3(Cout), dim3(256), lds, st, slab, p.nsplit, p.rows_pad, ktot,
+                               cin_tap, Cin, mask, inv_scale, dw, rmap, cmap);
+    } else if (!stem && Cin % 4 == 0 && (ksize == 1 || ksize == 3)) {
         long long total = (long long)Cout * (Cin / 4);
-        if (ksize == 3) launch_finish_vec<9>(sg, total, slab, p, ktot, cin_tap, Cout, Cin, mask, inv_scale, dw, st);
-        else launch_finish_vec<1>(sg, total, slab, p, ktot, cin_tap, Cout, Cin, mask, inv_scale, dw, st);
+        if (ksize == 3) launch_finish_vec<9>(sg, total, slab, p, ktot, cin_tap, Cout, Cin, mask, inv_scale, dw, rmap, cmap, st);
+        else launch_finish_vec<1>(sg, total, slab, p, ktot, cin_tap, Cout, Cin, mask, inv_scale, dw, rmap, cmap, st);
     } else {
         long long total = (long long)Cout * Cin * ksize * ksize;
 #define S_CASE(SG_)                                                                                                  \
     hipLaunchKernelGGL((wgrad_finish_kernel<SG_>), dim3((unsigned)((total + 256 / SG_ - 1) / (256 / SG_))), dim3(256), 0, \
-                       st, slab, p.nsplit, p.rows_pad, ktot, cin_tap, stem, Cout, Cin, ksize * ksize, mask, inv_scale, dw)
+                       st, slab, p.nsplit, p.rows_pad, ktot, cin_tap, stem, Cout, Cin, ksize * ksize, mask, inv_scale, dw, rmap, cmap)
         if (sg == 1) S_CASE(1);
         else if (sg == 8) S_CASE(8);
         else S_CASE(32);

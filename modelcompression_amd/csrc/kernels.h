@@ -80,7 +80,8 @@ bool mcamd_wgrad_use9(int ksize, int stem, int cout, int cin_tap, int W);
 WgradPlan mcamd_wgrad_plan9(long long P, int cout, int cin_tap);
 int mcamd_wgrad9_launch(const WgradArgs& w, const WgradPlan& p, int W, long long P, hipStream_t st);
 int mcamd_wgrad_finish_launch(const float* slab, const WgradPlan& p, int ktot, int cin_tap, int stem, int Cout, int Cin,
-                              int ksize, const float* mask, float inv_scale, float* dw, hipStream_t st);
+                              int ksize, const float* mask, float inv_scale, float* dw, const int* rmap, const int* cmap,
+                              hipStream_t st);
 int mcamd_colsum_launch(const half_t* dy, long long rows, int ld, int choff, int C, float inv_scale, float* out,
                         hipStream_t st);
 

@@ -248,7 +248,7 @@ class Engine:
             lay.gin = None
             if lay.li > 0:
                 lay.gin = torch.empty(lay.M * lay.tin.ld, dtype=ops.HALF, device=dev)
-            lay.perm = lay.perm32 = lay.in_perm = lay.g_rows = lay.g_cols = lay.mask_phys = None
+            lay.perm = lay.perm32 = lay.in_perm = lay.g_rows = lay.g_cols = None
             lay.n_act, lay.geom_act, lay.gather = lay.cout, lay.geom, False
             if not lay.is_last:
                 # zero-initialised: with filter compaction the convolution writes the kept channels only
@@ -260,9 +260,9 @@ class Engine:
                 if lay.out_t is None:
                     raise NotImplementedError("conv block %d output is never consumed" % lay.index)
         self.wgrad_ws = torch.empty(max(wbytes, 16), dtype=torch.uint8, device=dev)
-        self.dw_scratch = None            # weight gradient in physical channel order (compacted layers)
         self._mask_keys = None
         self.compact = os.environ.get("MCAMD_COMPACT", "1") == "1"
+        self.compact_gran = int(os.environ.get("MCAMD_COMPACT_GRAN", "0"))
         maxc = max(l.cout for l in self.layers)
         self.bwd_ws = torch.empty(ops.bn_act_bwd_workspace_bytes(maxc), dtype=torch.uint8, device=dev)
         self.params = list(model.parameters())
@@ -302,8 +302,9 @@ class Engine:
         return r
 
     def conv_flops(self, lay):
-        """Algorithmic FLOPs of one forward conv launch (2 * M * Cout * Cin * k*k, unpadded)."""
-        return 2.0 * lay.M * lay.cout * lay.cin * lay.k * lay.k
+        """Algorithmic FLOPs of one forward conv launch (2 * M * Cout * Cin * k*k, unpadded); with filter
+        compaction Cout is the number of filters the launch actually computes."""
+        return 2.0 * lay.M * lay.n_act * lay.cin * lay.k * lay.k
 
     # ------------------------------------------------------------------ weights
     def _signature(self):
@@ -328,12 +329,9 @@ class Engine:
             w = lay.conv.weight.data
             if w.dtype != torch.float32 or not w.is_contiguous():
                 raise McamdError("conv weights must be contiguous fp32 (master copy)")
-            if lay.gather:                   # physical channel order: kept filters first / permuted inputs
-                w = w[lay.g_rows[:, None], lay.g_cols[None, :]]
-                ops.pack_weights(lay.geom_act, w, lay.mask_phys, True, lay.wd is not None, lay.wp, lay.wd)
-            else:
-                mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
-                ops.pack_weights(lay.geom, w, mask, True, lay.wd is not None, lay.wp, lay.wd)
+            mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
+            # geom_act / g_rows / g_cols: physical channel order (kept filters first, permuted inputs); identity = None
+            ops.pack_weights(lay.geom_act, w, mask, True, lay.wd is not None, lay.wp, lay.wd, rows=lay.g_rows, cols=lay.g_cols)
         self._packed_sig = sig
         self.model._weights_dirty = False
 
@@ -356,7 +354,7 @@ class Engine:
         dev = self.device
         tperm = {-1: None}               # tensor id -> LongTensor physical position -> original channel (None = identity)
         by_ci = {lay.index: lay for lay in self.layers}
-        need_scratch, wbytes = 0, 16
+        wbytes = 16
         for ind, (t, _) in enumerate(self._bops):
             src = self._srcs[ind]
             if t == "convolutional":
@@ -369,7 +367,10 @@ class Engine:
                     alive = mask.reshape(lay.cout, -1).amax(1) != 0
                     keep = alive.float()
                     if self.compact and lay.bn is not None:
-                        n8 = min(lay.cout, ops.round_up(max(int(alive.sum()), 1), 8))
+                        # kept count rounded up so the kernels keep their tile shapes: whole 64-filter tiles
+                        # (the 9-tap wgrad and the 128-wide igemm tiles) where the layer has them
+                        gran = self.compact_gran or (64 if lay.cout >= 128 else 8)
+                        n8 = min(lay.cout, ops.round_up(max(int(alive.sum()), 1), gran))
                         if n8 < lay.cout:
                             perm = torch.cat((torch.nonzero(alive).flatten(), torch.nonzero(~alive).flatten()))
                             n_act = n8
@@ -380,13 +381,8 @@ class Engine:
                 lay.geom_act = lay.geom if perm is None else ops.geom(self.B, lay.H, lay.W, lay.k, lay.cin, n_act,
                                                                       lay.tin.ld, lay.tin.choff, lay.stem)
                 lay.gather = perm is not None or in_perm is not None
-                lay.g_rows = lay.g_cols = lay.mask_phys = None
-                if lay.gather:
-                    lay.g_rows = perm[:n_act] if perm is not None else torch.arange(lay.cout, device=dev)
-                    lay.g_cols = in_perm if in_perm is not None else torch.arange(lay.cin, device=dev)
-                    if mask is not None:
-                        lay.mask_phys = mask[lay.g_rows[:, None], lay.g_cols[None, :]].contiguous()
-                    need_scratch = max(need_scratch, n_act * lay.cin * lay.k * lay.k)
+                lay.g_rows = perm[:n_act].to(torch.int32).contiguous() if perm is not None else None
+                lay.g_cols = in_perm.to(torch.int32).contiguous() if in_perm is not None else None
                 if lay.bn is not None:
                     rows = ops.stats_rows(lay.geom_act)
                     if lay.stats.shape[0] != rows:
@@ -415,8 +411,6 @@ class Engine:
                 tperm[ind] = tperm[src[0]]
             else:
                 tperm[ind] = None
-        if need_scratch and (self.dw_scratch is None or self.dw_scratch.numel() < need_scratch):
-            self.dw_scratch = torch.empty(need_scratch, dtype=torch.float32, device=dev)
         if wbytes > self.wgrad_ws.numel():
             self.wgrad_ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
 
@@ -496,15 +490,13 @@ class Engine:
             mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
             dbias = gmap[id(lay.conv.bias)] if lay.conv.bias is not None else None
             if lay.gather:
-                # kept filters only, in physical channel order; scattered back to OIHW order (rows of removed
-                # filters are zero, as `grad * mask` makes them in the reference)
-                dwt = self.dw_scratch[:lay.n_act * lay.cin * lay.k * lay.k].view(lay.n_act, lay.cin, lay.k, lay.k)
-                self._timed('wgrad', lay, ops.conv_wgrad, lay.geom_act, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
-                            dwt, lay.mask_phys, S, dbias, self.wgrad_ws)
+                # kept filters only, in physical channel order; the finish kernel scatters to OIHW order.  Rows of
+                # removed filters are zero (as `grad * mask` makes them in the reference): zeroed here, not computed
                 gw = gmap[id(lay.conv.weight)]
                 if lay.perm is not None:
                     gw.zero_()
-                gw[lay.g_rows[:, None], lay.g_cols[None, :]] = dwt
+                self._timed('wgrad', lay, ops.conv_wgrad, lay.geom_act, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
+                            gw, mask, S, dbias, self.wgrad_ws, rows=lay.g_rows, cols=lay.g_cols)
             elif side is None:
                 self._timed('wgrad', lay, ops.conv_wgrad, lay.geom, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
                             gmap[id(lay.conv.weight)], mask, S, dbias, self.wgrad_ws)

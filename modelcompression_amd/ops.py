@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from ._lib import ConvGeom, ConvEpilogue, ActDesc, ActBwdDesc, check, ptr, stream_ptr
+from ._lib import ConvGeom, ConvEpilogue, ActDesc, ActBwdDesc, ChanMap, check, ptr, stream_ptr
 
 HALF = torch.float16
 SLACK = 64  # fp16 elements of zeroed slack after every activation buffer
@@ -53,8 +53,22 @@ def packed_elems(g):
     return int(lib.mcamd_packed_elems_fwd(C.byref(g))), int(lib.mcamd_packed_elems_dgrad(C.byref(g)))
 
 
-def pack_weights(g, w, mask=None, want_fwd=True, want_dgrad=True, out_fwd=None, out_dgrad=None):
-    """fp32 OIHW master (* mask) -> (fwd, dgrad) fp16 packings (layers.py:59 replacement)."""
+def _chan_map(g, rows, cols):
+    """mcamd_chan_map from optional int32 CUDA vectors (physical filter / input channel -> tensor index)."""
+    if rows is None and cols is None:
+        return None
+    m = ChanMap()
+    for name, v, n in (("rows", rows, g.cout), ("cols", cols, g.cin)):
+        if v is not None:
+            if v.dtype != torch.int32 or not v.is_cuda or not v.is_contiguous() or v.numel() != n:
+                raise L.McamdError("channel map `%s` must be a contiguous CUDA int32 vector of %d entries" % (name, n))
+            setattr(m, name, v.data_ptr())
+    return C.byref(m)
+
+
+def pack_weights(g, w, mask=None, want_fwd=True, want_dgrad=True, out_fwd=None, out_dgrad=None, rows=None, cols=None):
+    """fp32 OIHW master (* mask) -> (fwd, dgrad) fp16 packings (layers.py:59 replacement).
+    `rows` / `cols`: physical channel order of `g` (see mcamd_chan_map); w and mask stay in OIHW order."""
     _need_cuda(w, mask)
     assert w.dtype == torch.float32 and w.is_contiguous()
     nf, nd = packed_elems(g)
@@ -62,7 +76,7 @@ def pack_weights(g, w, mask=None, want_fwd=True, want_dgrad=True, out_fwd=None, 
         out_fwd = torch.empty(nf, dtype=HALF, device=w.device)
     if want_dgrad and not g.stem and out_dgrad is None:
         out_dgrad = torch.empty(nd, dtype=HALF, device=w.device)
-    check(L.lib().mcamd_pack_weights(C.byref(g), ptr(w), ptr(mask), ptr(out_fwd) if want_fwd else None,
+    check(L.lib().mcamd_pack_weights(C.byref(g), ptr(w), ptr(mask), _chan_map(g, rows, cols), ptr(out_fwd) if want_fwd else None,
                                      ptr(out_dgrad) if (want_dgrad and not g.stem) else None, stream_ptr()),
           "mcamd_pack_weights")
     return out_fwd, out_dgrad
@@ -126,10 +140,11 @@ def wgrad_workspace_bytes(g):
     return int(L.lib().mcamd_conv_wgrad_workspace_bytes(C.byref(g)))
 
 
-def conv_wgrad(g, x, dy, dy_ld, dy_choff, dw, mask=None, grad_scale=1.0, dbias=None, workspace=None):
+def conv_wgrad(g, x, dy, dy_ld, dy_choff, dw, mask=None, grad_scale=1.0, dbias=None, workspace=None, rows=None, cols=None):
+    """`rows` / `cols`: physical channel order of `g`; dw / mask stay OIHW and rows outside `rows` are not written."""
     if workspace is None:
         workspace = torch.empty(wgrad_workspace_bytes(g), dtype=torch.uint8, device=dw.device)
-    check(L.lib().mcamd_conv_wgrad(C.byref(g), ptr(x), ptr(dy), dy_ld, dy_choff, ptr(mask), None, grad_scale, ptr(dw),
+    check(L.lib().mcamd_conv_wgrad(C.byref(g), ptr(x), ptr(dy), dy_ld, dy_choff, ptr(mask), _chan_map(g, rows, cols), grad_scale, ptr(dw),
                                    ptr(dbias), ptr(workspace), workspace.numel(), stream_ptr()), "mcamd_conv_wgrad")
 
 

@@ -159,6 +159,52 @@ def test_conv_dgrad_wgrad(dev, case):
     assert rel_l2(db.cpu(), q16(gy).sum((0, 2, 3))) < TOL
 
 
+@pytest.mark.parametrize("k,cin,cout_full,n_phys", [(3, 64, 128, 64), (3, 40, 96, 24), (1, 256, 64, 40)])
+def test_channel_maps_pack_fwd_dgrad_wgrad(dev, k, cin, cout_full, n_phys):
+    """mcamd_chan_map: the kernels work on a PHYSICAL channel order (kept filters first, permuted inputs)
+    while weights, masks and weight gradients stay in the module's OIHW order."""
+    B, H, W = 2, 12, 20
+    gen = torch.Generator().manual_seed(31)
+    w = torch.randn(cout_full, cin, k, k, generator=gen) * 0.1
+    mask = (torch.rand(cout_full, cin, k, k, generator=gen) > 0.3).float()
+    rows = torch.randperm(cout_full, generator=gen)[:n_phys]          # physical filter n = tensor row rows[n]
+    cols = torch.randperm(cin, generator=gen)                         # physical input channel c = tensor column cols[c]
+    x_phys = torch.rand(B, cin, H, W, generator=gen)                  # activations already in physical order
+    gy = torch.randn(B, n_phys, H, W, generator=gen)
+    w_phys = (w * mask)[rows][:, cols]
+    xr = q16(x_phys).requires_grad_(True)
+    wr = q16(w_phys).requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 1, (k - 1) // 2)
+    yr.backward(q16(gy))
+    xb, ld = to_padded(x_phys.to(dev))
+    g = ops.geom(B, H, W, k, cin, n_phys, ld)
+    r32, c32 = rows.to(dev, torch.int32), cols.to(dev, torch.int32)
+    wp, wd = ops.pack_weights(g, w.to(dev).contiguous(), mask.to(dev).contiguous(), rows=r32, cols=c32)
+    y = torch.zeros(B, n_phys, H, W, device=dev)
+    ops.conv_fwd_nchw(g, xb, wp, y)
+    assert rel_l2(y.cpu(), yr.detach()) < TOL, "fwd through the maps"
+    dyb, dy_ld = to_padded(gy.to(dev))
+    dx = torch.zeros(B, cin, H, W, device=dev)
+    ops.conv_dgrad_nchw(g, dyb, dy_ld, 0, wd, dx)
+    assert rel_l2(dx.cpu(), xr.grad) < TOL, "dgrad through the maps"
+    dw = torch.full((cout_full, cin, k, k), 7.0, device=dev)          # rows outside `rows` must stay untouched
+    ops.conv_wgrad(g, xb, dyb, dy_ld, 0, dw, mask.to(dev).contiguous(), rows=r32, cols=c32)
+    ref = torch.full((cout_full, cin, k, k), 7.0)
+    scat = torch.zeros(n_phys, cin, k, k)
+    scat[:, cols] = wr.grad
+    ref[rows] = scat * mask[rows]
+    assert rel_l2(dw.cpu()[rows], ref[rows]) < TOL, "wgrad scattered to OIHW order"
+    untouched = torch.ones(cout_full, dtype=torch.bool)
+    untouched[rows] = False
+    assert bool((dw.cpu()[untouched] == 7.0).all())
+    assert bool((dw.cpu()[rows][mask[rows] == 0] == 0).all())
+    # rows-only and cols-only maps
+    wp2, _ = ops.pack_weights(g, w.to(dev).contiguous(), None, rows=r32)
+    y2 = torch.zeros(B, n_phys, H, W, device=dev)
+    ops.conv_fwd_nchw(g, xb, wp2, y2)
+    assert rel_l2(y2.cpu(), F.conv2d(q16(x_phys), q16(w[rows]), None, 1, (k - 1) // 2)) < TOL
+
+
 def test_wgrad_stem(dev):
     B, H, W, cout = 2, 24, 40, 32
     gen = torch.Generator().manual_seed(13)
