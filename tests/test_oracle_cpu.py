@@ -146,6 +146,19 @@ def test_percentile_restatement_vs_numpy():
                 assert got == ref and got.dtype == ref.dtype, (n, dt, q)
 
 
+def test_percentile_restatement_with_ties_vs_numpy():
+    """Runs of equal values (an already pruned tensor is half zeros) and the extreme percentiles."""
+    rng = np.random.default_rng(5)
+    for n in (8, 4097, 30000):
+        for dt in (np.float32, np.float64):
+            a = np.abs(rng.standard_normal(n)).astype(dt)
+            a[rng.random(n) < 0.5] = 0.0
+            a[: n // 8] = a[n // 2]                      # a second run of equal values
+            for q in (0, 1e-3, 25, 50, 50.001, 62.5, 99.999, 100):
+                got, ref = P.percentile_linear(a.copy(), q), np.percentile(a.copy(), q)
+                assert got == ref and got.dtype == ref.dtype, (n, dt, q)
+
+
 def test_float32_virtual_index_at_full_size():
     N = 50634592
     for q, k in [(20, 10126919), (40, 20253838), (60, 30380756), (70, 35444212), (75, 37975944), (80, 40507676),
