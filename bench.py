@@ -130,7 +130,9 @@ def main():
         model.set_masks(masks)
     if args.workload == "slim60":
         return bench_slim(args, model, dev, rank)
-    opt = torch.optim.SGD(model.parameters(), lr=1e-5, momentum=0.9, dampening=0, weight_decay=0.0005 * B)
+    # same update rule as train.py:144-147; torch's fused multi-tensor implementation (one kernel per dtype/device)
+    sgd_kw = {"fused": True} if os.environ.get("MCAMD_SGD_FUSED", "1") == "1" else {}
+    opt = torch.optim.SGD(model.parameters(), lr=1e-5, momentum=0.9, dampening=0, weight_decay=0.0005 * B, **sgd_kw)
     reducer = dp.attach(model) if world > 1 else None
     x = synthetic_batch(B, 416, 416, seed=rank, device=dev)   # resident in HBM before the timed region
 

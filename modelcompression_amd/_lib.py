@@ -40,6 +40,12 @@ class ChanMap(C.Structure):
     _fields_ = [("rows", C.c_void_p), ("cols", C.c_void_p)]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("mask", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_void_p), ("cols", C.c_void_p),
+                ("first_item", C.c_int64), ("cout", C.c_int32), ("cin", C.c_int32), ("ksize", C.c_int32),
+                ("dgrad", C.c_int32)]
+
+
 class ActBwdDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
                 ("y", C.c_void_p), ("y_ld", C.c_int32), ("y_choff", C.c_int32),
@@ -66,6 +72,7 @@ SIGNATURES = {
     "mcamd_packed_elems_fwd": (_I64, [C.POINTER(ConvGeom)]),
     "mcamd_packed_elems_dgrad": (_I64, [C.POINTER(ConvGeom)]),
     "mcamd_pack_weights": (C.c_int, [C.POINTER(ConvGeom), _P, _P, C.POINTER(ChanMap), _P, _P, _P]),
+    "mcamd_pack_weights_many": (C.c_int, [_P, _I32, _I64, _P]),
     "mcamd_conv_fwd": (C.c_int, [C.POINTER(ConvGeom), _P, _P, C.POINTER(ConvEpilogue), _P]),
     "mcamd_conv_dgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _I32, _I32, _P, C.POINTER(ConvEpilogue), _P]),
     "mcamd_conv_wgrad_workspace_bytes": (_SZ, [C.POINTER(ConvGeom)]),

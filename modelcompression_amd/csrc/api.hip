@@ -66,6 +66,8 @@ extern "C" int64_t mcamd_packed_elems_dgrad(const mcamd_conv_geom* g) {
 // ---------------------------------------------------------------------------------------
 // weight packing
 // ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int round_up_dev(int v, int m) { return (v + m - 1) / m * m; }
+
 __global__ __launch_bounds__(256) void pack_fwd_kernel(const float* w, const float* mask, half_t* wp, int Cout, int Cin,
                                                        int ks, int cin_tap, int stem, long long total, int ktot,
                                                        const int* rmap, const int* cmap) {
@@ -146,6 +148,60 @@ extern "C" int mcamd_pack_weights(const mcamd_conv_geom* g, const float* w_oihw,
                            g->cout, g->cin, g->ksize, cout_p_of(g), total, ktot, rmap, cmap);
     }
     MCAMD_LAUNCH_CHECK("pack_weights");
+    return MCAMD_OK;
+}
+
+// All layers in one launch.  item = (n, c) of one job; lanes run over c (forward layout) or n (dgrad layout) so
+// that the k*k fp16 stores of a wave are contiguous, and each lane reads its k*k taps as one 36-byte run.
+__global__ __launch_bounds__(256) void pack_many_kernel(const mcamd_pack_job* jobs, int njobs, long long total) {
+    for (long long item = (long long)blockIdx.x * 256 + threadIdx.x; item < total; item += (long long)gridDim.x * 256) {
+        int lo = 0, hi = njobs - 1;          // last job whose first_item <= item
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].first_item <= item) lo = mid;
+            else hi = mid - 1;
+        }
+        const mcamd_pack_job j = jobs[lo];
+        const long long r = item - j.first_item;
+        int n, c;
+        if (j.dgrad) {
+            c = (int)(r / j.cout);
+            n = (int)(r - (long long)c * j.cout);
+        } else {
+            n = (int)(r / j.cin);
+            c = (int)(r - (long long)n * j.cin);
+        }
+        const int ks = j.ksize, kk = ks * ks;
+        const int ns = j.rows ? j.rows[n] : n, cs = j.cols ? j.cols[c] : c;
+        const long long src = ((long long)ns * j.cin + cs) * kk;
+        half_t* dst = (half_t*)j.dst;
+        if (j.dgrad) {
+            const int cout_p = round_up_dev(j.cout, 32);
+            const long long base = (long long)c * kk * cout_p + n;
+            for (int t = 0; t < kk; ++t) {   // flipped taps
+                float v = j.w[src + kk - 1 - t];
+                if (j.mask) v *= j.mask[src + kk - 1 - t];
+                dst[base + (long long)t * cout_p] = (half_t)v;
+            }
+        } else {
+            const int cin_tap = round_up_dev(j.cin, 32);
+            const long long base = (long long)n * kk * cin_tap + c;
+            for (int t = 0; t < kk; ++t) {
+                float v = j.w[src + t];
+                if (j.mask) v *= j.mask[src + t];
+                dst[base + (long long)t * cin_tap] = (half_t)v;
+            }
+        }
+    }
+}
+
+extern "C" int mcamd_pack_weights_many(const mcamd_pack_job* jobs_dev, int32_t njobs, int64_t total_items, void* stream) {
+    MCAMD_REQUIRE(jobs_dev && njobs > 0 && total_items > 0, "pack_weights_many: empty job table");
+    long long grid = (total_items + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(pack_many_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs,
+                       (long long)total_items);
+    MCAMD_LAUNCH_CHECK("pack_weights_many");
     return MCAMD_OK;
 }
 

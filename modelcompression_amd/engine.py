@@ -239,8 +239,9 @@ class Engine:
         for lay in self.layers:
             g = lay.geom
             nf, nd = ops.packed_elems(g)
-            lay.wp = torch.empty(nf, dtype=ops.HALF, device=dev)
-            lay.wd = torch.empty(nd, dtype=ops.HALF, device=dev) if (nd and lay.li > 0) else None
+            # zero-initialised: the one-launch packer writes real entries only (pad rows / channels stay zero)
+            lay.wp = torch.zeros(nf, dtype=ops.HALF, device=dev)
+            lay.wd = torch.zeros(nd, dtype=ops.HALF, device=dev) if (nd and lay.li > 0) else None
             wbytes = max(wbytes, ops.wgrad_workspace_bytes(g))
             lay.cout_p = ops.round_up(lay.cout, 32)
             lay.dy = ops.alloc_padded(B, lay.H, lay.W, lay.cout_p, dev)
@@ -261,6 +262,7 @@ class Engine:
                     raise NotImplementedError("conv block %d output is never consumed" % lay.index)
         self.wgrad_ws = torch.empty(max(wbytes, 16), dtype=torch.uint8, device=dev)
         self._mask_keys = None
+        self._pack_key, self._pack_table, self._pack_keep = None, None, []
         self.compact = os.environ.get("MCAMD_COMPACT", "1") == "1"
         self.compact_gran = int(os.environ.get("MCAMD_COMPACT_GRAN", "0"))
         maxc = max(l.cout for l in self.layers)
@@ -325,13 +327,37 @@ class Engine:
         if mkeys != self._mask_keys:         # masks are static during retraining: planned once
             self._update_compaction()
             self._mask_keys = mkeys
+            self._pack_key = None
+            for lay in self.layers:          # the packed shapes may have shrunk: stale entries must not survive
+                lay.wp.zero_()
+                if lay.wd is not None:
+                    lay.wd.zero_()
+        # geom_act / g_rows / g_cols: physical channel order (kept filters first, permuted inputs); identity = None
+        tkey = tuple((s_[0], None if s_[2] is None else s_[2][0]) for s_ in sig)
+        if tkey != self._pack_key:          # weight / mask storage moved, or the compaction changed: new job table
+            jobs, self._pack_keep = [], []
+            for lay in self.layers:
+                w = lay.conv.weight.data
+                if w.dtype != torch.float32 or not w.is_contiguous():
+                    raise McamdError("conv weights must be contiguous fp32 (master copy)")
+                mask = lay.conv.mask if lay.conv.mask_flag else None
+                if mask is not None and not mask.is_contiguous():
+                    raise McamdError("conv masks must be contiguous")
+                if lay.stem:
+                    continue
+                self._pack_keep += [w, mask]
+                common = dict(w=w, mask=mask, rows=lay.g_rows, cols=lay.g_cols, cout=lay.n_act, cin=lay.cin, ksize=lay.k)
+                jobs.append(dict(common, dst=lay.wp, dgrad=False))
+                if lay.wd is not None:
+                    jobs.append(dict(common, dst=lay.wd, dgrad=True))
+            self._pack_table = ops.pack_table(jobs, self.device) if jobs else None
+            self._pack_key = tkey
         for lay in self.layers:
-            w = lay.conv.weight.data
-            if w.dtype != torch.float32 or not w.is_contiguous():
-                raise McamdError("conv weights must be contiguous fp32 (master copy)")
-            mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
-            # geom_act / g_rows / g_cols: physical channel order (kept filters first, permuted inputs); identity = None
-            ops.pack_weights(lay.geom_act, w, mask, True, lay.wd is not None, lay.wp, lay.wd, rows=lay.g_rows, cols=lay.g_cols)
+            if lay.stem:
+                mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
+                ops.pack_weights(lay.geom_act, lay.conv.weight.data, mask, True, False, lay.wp, None, rows=lay.g_rows)
+        if self._pack_table is not None:
+            ops.pack_many(*self._pack_table)
         self._packed_sig = sig
         self.model._weights_dirty = False
 

@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from ._lib import ConvGeom, ConvEpilogue, ActDesc, ActBwdDesc, ChanMap, check, ptr, stream_ptr
+from ._lib import ConvGeom, ConvEpilogue, ActDesc, ActBwdDesc, ChanMap, PackJob, check, ptr, stream_ptr
 
 HALF = torch.float16
 SLACK = 64  # fp16 elements of zeroed slack after every activation buffer
@@ -80,6 +80,29 @@ def pack_weights(g, w, mask=None, want_fwd=True, want_dgrad=True, out_fwd=None, 
                                      ptr(out_dgrad) if (want_dgrad and not g.stem) else None, stream_ptr()),
           "mcamd_pack_weights")
     return out_fwd, out_dgrad
+
+
+def pack_table(jobs, device):
+    """jobs: list of dicts(w, mask, dst, rows, cols, cout, cin, ksize, dgrad) -> (device table, njobs, total items)
+    for `pack_many` (mcamd_pack_job array).  The tensors must stay alive and in place while the table is used."""
+    arr = (PackJob * len(jobs))()
+    total = 0
+    for a, j in zip(arr, jobs):
+        _need_cuda(j["w"], j["dst"])
+        assert j["w"].dtype == torch.float32 and j["w"].is_contiguous() and j["dst"].dtype == HALF
+        a.w, a.dst = j["w"].data_ptr(), j["dst"].data_ptr()
+        a.mask = j["mask"].data_ptr() if j.get("mask") is not None else None
+        a.rows = j["rows"].data_ptr() if j.get("rows") is not None else None
+        a.cols = j["cols"].data_ptr() if j.get("cols") is not None else None
+        a.first_item, a.cout, a.cin, a.ksize, a.dgrad = total, j["cout"], j["cin"], j["ksize"], 1 if j["dgrad"] else 0
+        total += j["cout"] * j["cin"]
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return host.to(device), len(jobs), total
+
+
+def pack_many(table, njobs, total):
+    """Every (non-stem) layer's fwd + dgrad packing in one launch; pads of the destinations must already be zero."""
+    check(L.lib().mcamd_pack_weights_many(ptr(table), njobs, total, stream_ptr()), "mcamd_pack_weights_many")
 
 
 def tile_info(g, dgrad=False):

@@ -91,7 +91,7 @@ class YOLOv2Train():
         init_epoch = int(self.model.seen / nsamples)
         LR = 0.00001
         optimizer = optim.SGD(self.model.parameters(), lr=LR, momentum=momentum, dampening=0,
-                              weight_decay=decay * self.batch_size)
+                              weight_decay=decay * self.batch_size, fused=True)   # same rule (train.py:144-147), one kernel
         self.optimizer = optimizer
         reducer = dp.attach(self.model) if world > 1 else None
 

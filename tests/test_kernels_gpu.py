@@ -205,6 +205,31 @@ def test_channel_maps_pack_fwd_dgrad_wgrad(dev, k, cin, cout_full, n_phys):
     assert rel_l2(y2.cpu(), F.conv2d(q16(x_phys), q16(w[rows]), None, 1, (k - 1) // 2)) < TOL
 
 
+def test_pack_many_equals_per_layer_pack(dev):
+    """mcamd_pack_weights_many (every layer in one launch) writes exactly what mcamd_pack_weights writes."""
+    gen = torch.Generator().manual_seed(41)
+    cases = [(3, 64, 128, False, False), (1, 256, 64, True, False), (3, 40, 24, True, True), (1, 8, 125, False, True),
+             (3, 1280, 72, True, True)]
+    jobs, want, keep = [], [], []
+    for k, cin, cout, masked, mapped in cases:
+        cout_full = cout + 16 if mapped else cout
+        w = (torch.randn(cout_full, cin, k, k, generator=gen) * 0.1).to(dev).contiguous()
+        mask = (torch.rand(cout_full, cin, k, k, generator=gen) > 0.3).float().to(dev).contiguous() if masked else None
+        rows = torch.randperm(cout_full, generator=gen)[:cout].to(dev, torch.int32) if mapped else None
+        cols = torch.randperm(cin, generator=gen).to(dev, torch.int32) if mapped else None
+        g = ops.geom(2, 8, 8, k, cin, cout, ops.round_up(cin, 32))
+        wp, wd = ops.pack_weights(g, w, mask, rows=rows, cols=cols)
+        want += [wp, wd]
+        mine = [torch.zeros_like(wp), torch.zeros_like(wd)]
+        keep += [w, mask, rows, cols] + mine
+        for dst, dg in zip(mine, (False, True)):
+            jobs.append(dict(w=w, mask=mask, rows=rows, cols=cols, cout=cout, cin=cin, ksize=k, dst=dst, dgrad=dg))
+    table = ops.pack_table(jobs, dev)
+    ops.pack_many(*table)
+    for j, ref in zip(jobs, want):
+        assert torch.equal(j["dst"], ref), (j["cout"], j["cin"], j["ksize"], j["dgrad"])
+
+
 def test_wgrad_stem(dev):
     B, H, W, cout = 2, 24, 40, 32
     gen = torch.Generator().manual_seed(13)
