@@ -107,9 +107,12 @@ typedef struct mcamd_chan_map {
 
 /* OIHW fp32 master (optionally * mask) -> fp16 kernel layouts.  Replaces the per-forward
  * `self.weight * mask_var` of layers.py:59 (done once per optimizer step here).
- *   fwd  : [Npad][t*cin + c]  = w[n][c][ty][tx],  t = ty*k + tx;  Npad = roundup(cout,256); pad rows zero
+ *   fwd  : [Npad][kpos(t, c)] = w[n][c][ty][tx],  t = ty*k + tx;  Npad = roundup(cout,256); pad rows zero
  *          (stem: [Npad][ty*32 + tx*4 + c], other slots zero)
- *   dgrad: [Cpad][t*cout_p + n] = w[n][c][k-1-ty][k-1-tx]; cout_p = roundup(cout,32); Cpad = roundup(cin,256)
+ *   dgrad: [Cpad][kpos(t, n)] = w[n][c][k-1-ty][k-1-tx]; cout_p = roundup(cout,32); Cpad = roundup(cin,256)
+ *   kpos(t, c) = (c / kb) * k*k*kb + t * kb + c % kb over the padded channel count chp (cin_tap = roundup(cin,32)
+ *   or cout_p), kb = 64 if chp % 64 == 0 else 32: the K axis runs [channel block][tap][channel in block], so the
+ *   k*k shifted reads of one activation line are consecutive K chunks (L2 hits instead of k*k streams).
  * Either destination may be NULL.  `map` (may be NULL): gather rows / columns of w and mask, see mcamd_chan_map. */
 int mcamd_pack_weights(const mcamd_conv_geom* g, const float* w_oihw, const float* mask_oihw,
                        const mcamd_chan_map* map, void* wp_fwd, void* wp_dgrad, void* stream);

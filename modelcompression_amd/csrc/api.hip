@@ -67,6 +67,15 @@ extern "C" int64_t mcamd_packed_elems_dgrad(const mcamd_conv_geom* g) {
 // weight packing
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ int round_up_dev(int v, int m) { return (v + m - 1) / m * m; }
+// K order of the packed matrices: [channel block][tap][channel inside the block].  All taps of a 64-channel
+// block are consecutive K chunks, so the nine shifted reads of the same activation lines follow each other
+// closely and hit L2 instead of streaming the whole activation tile nine times from the Infinity Cache.
+__host__ __device__ __forceinline__ int kblock_of(int ch_padded) { return ch_padded % 64 == 0 ? 64 : 32; }
+// position of (tap t, channel c) inside one packed row of `taps` taps x `chp` padded channels
+__host__ __device__ __forceinline__ int kpos(int t, int c, int taps, int chp) {
+    const int kb = kblock_of(chp);
+    return (c / kb) * taps * kb + t * kb + c % kb;
+}
 
 __global__ __launch_bounds__(256) void pack_fwd_kernel(const float* w, const float* mask, half_t* wp, int Cout, int Cin,
                                                        int ks, int cin_tap, int stem, long long total, int ktot,
@@ -85,8 +94,10 @@ __global__ __launch_bounds__(256) void pack_fwd_kernel(const float* w, const flo
                 c = r & 3;
                 ok = tx < 3 && c < 3;
             } else {
-                int t = k / cin_tap;
-                c = k - t * cin_tap;
+                const int kb = kblock_of(cin_tap), blk = ks * ks * kb;
+                const int cb = k / blk, r = k - cb * blk;
+                const int t = r / kb;
+                c = cb * kb + (r - t * kb);
                 ty = t / ks;
                 tx = t - ty * ks;
                 ok = c < Cin;
@@ -108,8 +119,10 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* w, const f
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         int c = (int)(idx / ktot);
         int k = (int)(idx - (long long)c * ktot);
-        int t = k / cout_p;
-        int n = k - t * cout_p;
+        const int kb = kblock_of(cout_p), blk = ks * ks * kb;
+        const int nb = k / blk, r = k - nb * blk;
+        int t = r / kb;
+        int n = nb * kb + (r - t * kb);
         float v = 0.f;
         if (c < Cin && n < Cout) {
             int ty = t / ks, tx = t - ty * ks;
@@ -177,19 +190,19 @@ __global__ __launch_bounds__(256) void pack_many_kernel(const mcamd_pack_job* jo
         half_t* dst = (half_t*)j.dst;
         if (j.dgrad) {
             const int cout_p = round_up_dev(j.cout, 32);
-            const long long base = (long long)c * kk * cout_p + n;
+            const long long base = (long long)c * kk * cout_p;
             for (int t = 0; t < kk; ++t) {   // flipped taps
                 float v = j.w[src + kk - 1 - t];
                 if (j.mask) v *= j.mask[src + kk - 1 - t];
-                dst[base + (long long)t * cout_p] = (half_t)v;
+                dst[base + kpos(t, n, kk, cout_p)] = (half_t)v;
             }
         } else {
             const int cin_tap = round_up_dev(j.cin, 32);
-            const long long base = (long long)n * kk * cin_tap + c;
+            const long long base = (long long)n * kk * cin_tap;
             for (int t = 0; t < kk; ++t) {
                 float v = j.w[src + t];
                 if (j.mask) v *= j.mask[src + t];
-                dst[base + (long long)t * cin_tap] = (half_t)v;
+                dst[base + kpos(t, c, kk, cin_tap)] = (half_t)v;
             }
         }
     }
@@ -308,6 +321,7 @@ extern "C" int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const voi
     a.N = g->cout;
     a.cin_tap = cin_tap_of(g);
     a.ntaps = ntaps_of(g);
+    a.kb = kblock_of(a.cin_tap);
     a.ktot = a.ntaps * a.cin_tap;
     fill_taps(g->ksize, g->stem, a.x_row_stride, g->x_ld, a.tap_off);
     const bool nine = epi && mcamd_igemm9_ok(g->ksize, g->stem, g->cout, a.cin_tap, g->W, epi->mode);
@@ -339,6 +353,7 @@ extern "C" int mcamd_conv_dgrad(const mcamd_conv_geom* g, const void* dy, int32_
     a.N = g->cin;
     a.cin_tap = cout_p;
     a.ntaps = g->ksize * g->ksize;
+    a.kb = kblock_of(a.cin_tap);
     a.ktot = a.ntaps * a.cin_tap;
     fill_taps(g->ksize, 0, a.x_row_stride, dy_ld, a.tap_off);
     MCAMD_REQUIRE(epi && epi->mode != MCAMD_EPI_PAD_F16 && !epi->stats, "conv_dgrad: epilogue must be mode 0 (no stats) or 1");

@@ -30,7 +30,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 template <int BM, int BN, int WM, int WN, int BK, int NSTAGE, int EPI>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64,
-                              ((BM / WM) * (BN / WN) >= 8 ? 2 : (BN >= 128 ? (NSTAGE * BK <= 96 ? 3 : 2) : (BN >= 64 ? 3 : 4))))
+                              (WM * WN >= 128 * 128 ? 1 :   // 256 accumulator registers per lane: one wave per SIMD
+                               (BM / WM) * (BN / WN) >= 8 ? 2 : (BN >= 128 ? (NSTAGE * BK <= 96 ? 3 : 2) : (BN >= 64 ? 3 : 4))))
 void igemm_kernel(IgemmArgs a) {
     constexpr int WAVES_N = BN / WN;
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
@@ -114,8 +115,11 @@ void igemm_kernel(IgemmArgs a) {
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         auto stage = [&](int q, int buf) {
-            int tap = q / cpt;
-            int koff = a.tap_off[tap] + (q - tap * cpt) * BK;
+            // packed K order [channel block of a.kb][tap][a.kb channels]: chunk q -> (block, tap, sub-chunk)
+            const int sub = a.kb / BK > 0 ? a.kb / BK : 1, per_block = a.ntaps * sub;
+            const int cb = q / per_block, r = q - cb * per_block;
+            const int tap = r / sub;
+            int koff = a.tap_off[tap] + cb * a.kb + (r - tap * sub) * BK;
             char* sa = smem + buf * STAGE_BYTES;
             char* sb = sa + A_SLOTS * 16;
 #pragma unroll
@@ -145,11 +149,32 @@ void igemm_kernel(IgemmArgs a) {
             else if (inflight == 1) wait_vmcnt<DMIN>();
             else wait_vmcnt<(NSTAGE > 3 ? 2 * DMIN : DMIN)>();
             __builtin_amdgcn_s_barrier();  // chunk q landed for every wave; every wave is done reading chunk q-1
-            if (q + NSTAGE - 1 < nchunks) {
-                int ns = sidx + NSTAGE - 1;
-                if (ns >= NSTAGE) ns -= NSTAGE;
-                stage(q + NSTAGE - 1, ns);
-            }
+            // One wave per SIMD (128x128 wave tiles): nothing else hides the issue cost of the DMA instructions, so
+            // they are spread between the MFMAs of the first half of the chunk instead of issued in one block.
+            constexpr bool SPREAD = (TM * TN == 16);
+            const bool more = q + NSTAGE - 1 < nchunks;
+            int ns = sidx + NSTAGE - 1;
+            if (ns >= NSTAGE) ns -= NSTAGE;
+            if (!SPREAD && more) stage(q + NSTAGE - 1, ns);
+            auto stage_piece = [&](int piece) {     // piece in [0, A_IT + B_IT)
+                // issued unconditionally (straight-line loop body keeps the accumulators in place): past the last chunk
+                // the last chunk is fetched again into a ring slot nobody reads any more
+                const int qn = more ? q + NSTAGE - 1 : nchunks - 1;
+                const int sub = a.kb / BK > 0 ? a.kb / BK : 1, per_block = a.ntaps * sub;
+                const int cb = qn / per_block, r = qn - cb * per_block;
+                const int tap = r / sub;
+                const int koff = a.tap_off[tap] + cb * a.kb + (r - tap * sub) * BK;
+                char* sa2 = smem + ns * STAGE_BYTES;
+                char* sb2 = sa2 + A_SLOTS * 16;
+                if (piece < A_IT) {
+                    const int wslot = piece * NT + wave * 64;
+                    if (wslot < A_SLOTS) glds16(a.x + abase[piece] + koff, sa2 + wslot * 16);
+                } else {
+                    const int it = piece - A_IT;
+                    const int wslot = it * NT + wave * 64;
+                    if (wslot < B_SLOTS) glds16(a.w + bbase[it] + (long long)qn * BK, sb2 + wslot * 16);
+                }
+            };
             const char* sa = smem + sidx * STAGE_BYTES;
             const char* sb = sa + A_SLOTS * 16;
             sidx = sidx + 1 == NSTAGE ? 0 : sidx + 1;
@@ -184,8 +209,16 @@ void igemm_kernel(IgemmArgs a) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                    for (int j = 0; j < TN; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s & M1][i], bf[s & M1][j], acc[i][j], 0, 0, 0);
+                        if (SPREAD) {
+                            // pieces per MFMA so that all of them are issued within the first half of the chunk
+                            constexpr int NP = A_IT + B_IT, SLOTS = (KS / 2 > 0 ? KS / 2 : 1) * TM * TN;
+                            constexpr int EVERY = SLOTS / NP > 0 ? SLOTS / NP : 1;
+                            const int m = s * TM * TN + i * TN + j;
+                            if (m % EVERY == EVERY - 1 && m / EVERY < NP) stage_piece(m / EVERY);
+                        }
+                    }
                 if (NSET == 2) __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -302,6 +335,7 @@ void igemm_kernel(IgemmArgs a) {
 // ---------------------------------------------------------------------------------------
 struct TileCfg {
     int bm, bn, bk;
+    int kind;   // 0: igemm_kernel<...>, 2: igemm_pp_kernel (256x256 ping-pong, conv_igemm_pp.hip)
 };
 
 static int env_int(const char* name, int dflt) {
@@ -315,6 +349,18 @@ static int env_int(const char* name, int dflt) {
 // (rate of the tile shape) x (fill of the last round of workgroups).
 static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot) {
     TileCfg t;
+    t.kind = 0;
+    // 256x256 ping-pong form (one workgroup per CU).  MCAMD_PP: 0 never, 1 by the cost rule below, 2 whenever legal.
+    {
+        const int pp = env_int("MCAMD_PP", 0);
+        if (pp && ktot >= 256 && n >= 128 && M >= 256) {
+            bool use = pp == 2;
+            if (use) {
+                t.bm = 256, t.bn = 256, t.bk = 32, t.kind = 2;
+                return t;
+            }
+        }
+    }
     int best = 128, waste = round_up_int(n, 128);
     for (int bn = 64; bn >= 32; bn /= 2)
         if (round_up_int(n, bn) < waste) {
@@ -359,9 +405,9 @@ static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot) {
     return t;
 }
 
-void mcamd_igemm_tile(long long M, int n, int cin_tap, int ktot, int out[3]) {
+void mcamd_igemm_tile(long long M, int n, int cin_tap, int ktot, int out[4]) {
     TileCfg t = pick_tile(M, n, cin_tap, ktot);
-    out[0] = t.bm, out[1] = t.bn, out[2] = t.bk;
+    out[0] = t.bm, out[1] = t.bn, out[2] = t.bk, out[3] = t.kind;
 }
 
 static int igemm_mtiles(long long M, int bm) { return (int)((M + bm - 1) / bm); }
@@ -371,7 +417,7 @@ int mcamd_igemm_rows(long long M, int n, int cin_tap, int ktot) {
     TileCfg t = pick_tile(M, n, cin_tap, ktot);
     int ntiles = (n + t.bn - 1) / t.bn;
     int mtiles = igemm_mtiles(M, t.bm);
-    int target = env_int("MCAMD_IGEMM_WGS", 2048);
+    int target = t.kind == 2 ? 256 : env_int("MCAMD_IGEMM_WGS", 2048);   // ping-pong: one workgroup per CU, persistent
     int p = target / ntiles;
     if (p < 1) p = 1;
     if (p > mtiles) p = mtiles;
@@ -414,6 +460,7 @@ int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st) {
     a.num_pslots = rows;
     a.num_ntiles = ntiles;
     a.xcd_order = env_int("MCAMD_XCD_ORDER", 1);
+    if (t.kind == 2) return mcamd_igemm_pp_launch(a, rows, ntiles, st);
     const int stages = env_int("MCAMD_STAGES", t.bk == 32 ? 3 : 2);
 #define I_CASE(BN_, WM_, WN_, BK_, ST_)                              \
     if (!done && t.bm == 128 && t.bn == BN_ && t.bk == BK_ && stages == ST_) { \
@@ -424,6 +471,7 @@ int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st) {
     if (t.bm == 192 && t.bn == 128 && t.bk == 64) { launch_one<192, 128, 96, 64, 64, 2>(a, rows, ntiles, st); done = true; }
     if (!done && t.bm == 256 && t.bn == 256 && t.bk == 32) { launch_one<256, 256, 128, 64, 32, 4>(a, rows, ntiles, st); done = true; }
     if (!done && t.bm == 256 && t.bn == 128 && t.bk == 32) { launch_one<256, 128, 64, 64, 32, 4>(a, rows, ntiles, st); done = true; }
+    if (!done && t.bm == 256 && t.bn == 256 && env_int("MCAMD_BIG4", 0)) { launch_one<256, 256, 128, 128, 64, 2>(a, rows, ntiles, st); done = true; }
     if (!done && t.bm == 256 && t.bn == 256) { launch_one<256, 256, 128, 64, 64, 2>(a, rows, ntiles, st); done = true; }
     if (!done && t.bm == 256 && t.bn == 128) { launch_one<256, 128, 64, 64, 64, 2>(a, rows, ntiles, st); done = true; }
     if (!done && t.bn == 128 && env_int("MCAMD_WAVES", 4) == 8) {   // 8-wave workgroups, one per CU

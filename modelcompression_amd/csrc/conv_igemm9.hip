@@ -57,9 +57,9 @@ __global__ __launch_bounds__(256, 2) void igemm9_kernel(Igemm9Args a) {
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         auto stage_b = [&](int u, int buf) {
-            // packed K index of unit u = (tap, chunk): tap*cin_tap + chunk*64
+            // packed K index of unit u = (tap, chunk)
             const int c = u / 9, tap = u - c * 9;
-            const long long koff = (long long)tap * a.cin_tap + c * BK;
+            const long long koff = ((long long)c * 9 + tap) * BK;   // packed K order [64-channel block][tap][64]
             char* sb = bbuf + buf * B_BYTES;
 #pragma unroll
             for (int it = 0; it < 4; ++it) glds16(a.w + bbase[it] + koff, sb + (it * NT + wave * 64) * 16);

@@ -1,0 +1,365 @@
+// Implicit-GEMM convolution, 256x256 "ping-pong" form (forward and dgrad of the wide layers).
+//
+// Why a second form: the L2 -> LDS operand stream of a CU tops out near 70 GB/s (MI355X_MICROARCH.md,
+// "Indexed rows: gather into LDS"), so a tile's MFMA work per staged byte, BM*BN/(BM+BN), decides
+// whether the matrix cores or the DMA path is the bound.  128x128 (64) and 192x128 (77) are DMA-bound;
+// 256x256 (128) is not -- but it is one workgroup per CU, so nothing outside the workgroup hides its
+// stalls.  Here the workgroup hides them itself:
+//
+//   * 8 waves = 2 (M) x 4 (N), wave tile 128x64 (128 accumulator registers), one wave of each GROUP
+//     (waves 0-3 / waves 4-7) per SIMD;
+//   * K advances in chunks of 32; a chunk is two barrier-delimited PHASES per wave:
+//         memory phase : wait (counted vmcnt) until chunk p+1 has landed, read the 12 fragments of
+//                        chunk p, retire them (lgkmcnt 0)
+//         s_barrier
+//         matrix phase : 16 x v_mfma_f32_32x32x16_f16, with the 4 LDS-DMA instructions of chunk p+3
+//                        issued between them (all 8 waves feed the DMA path continuously)
+//         s_barrier
+//   * group 1 executes ONE extra s_barrier before its first phase (and group 0 one after its last), so
+//     the groups run half a chunk apart: while one group's waves multiply, the other group's waves on
+//     the same SIMDs issue their DMAs and LDS reads.
+//   * 4-deep LDS ring of 32 KB stages (128 KB); three chunks are in flight across the barriers.
+//
+// Ordering rules that make the ring safe (one barrier episode = every wave of the workgroup):
+//   RAW  chunk c is read in memory phase c.  Every wave waited for its own DMA pieces of chunk c in
+//        memory phase c-1, i.e. before the first barrier of that phase; the read happens after the
+//        second barrier of phase c-1.  For the group that runs half a chunk later the same two
+//        barriers are one episode further on, still in that order.
+//   WAR  the DMA of chunk p+3 overwrites the ring slot of chunk p-1.  Both groups retired their reads
+//        of chunk p-1 (lgkmcnt 0) BEFORE the first barrier of their phase p-1; the DMA is issued in
+//        matrix phase p, three (group 0) or more barrier episodes later.
+// The accumulation order over K equals igemm_kernel's, so raw outputs are bit-identical to it
+// (tests/test_kernels_gpu.py::test_pingpong_*).
+//
+// Operand addressing, LDS swizzle (on the DMA source), persistent M tiles per N tile, BatchNorm partial
+// sums and the epilogues are those of conv_igemm.hip.  Replaces F.conv2d at reference
+// src/pruning/weightPruning/layers.py:60-64 and its autograd input gradient.
+#include "kernels.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 32, NST = 4;
+constexpr int WM = 128, WN = 64, WAVES_N = BN / WN;          // 2 x 4 waves
+constexpr int NT = 512;
+constexpr int CPR = BK / 8;                                   // 16-byte chunks per LDS row (64-byte rows)
+constexpr int A_SLOTS = BM * CPR, B_SLOTS = BN * CPR;
+constexpr int A_IT = A_SLOTS / NT, B_IT = B_SLOTS / NT;       // 2 + 2 DMA instructions per wave per chunk
+constexpr int DPC = A_IT + B_IT;
+constexpr int TM = WM / 32, TN = WN / 32;                     // 4 x 2 accumulator blocks
+constexpr int STAGE_BYTES = (A_SLOTS + B_SLOTS) * 16;         // 32 KB
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+}  // namespace
+
+// DBG (timing experiments only, results are wrong): 1 = no DMA inside the K loop, 2 = no fragment reads
+template <int EPI, int DBG = 0>
+__global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int group = wave >> 2;   // waves 0-3 / 4-7: one of each per SIMD
+
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int nt = jb % a.num_ntiles;
+    const int pslot = (jb / a.num_ntiles) * 8 + xcd;
+    if (pslot >= a.num_pslots) return;
+    const int nchunks = a.ktot / BK;
+    const int cpt = a.cin_tap / BK;
+
+    long long bbase[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int slot = it * NT + tid;
+        const int row = slot / CPR, phys = slot % CPR;
+        bbase[it] = (long long)(nt * BN + row) * a.ktot + (phys ^ swz<CPR>(row)) * 8;
+    }
+
+    float s1[TN], s2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
+
+    for (int mt = pslot; mt < a.num_mtiles; mt += a.num_pslots) {
+        long long abase[A_IT];
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int slot = it * NT + tid;
+            const int row = slot / CPR, phys = slot % CPR;
+            int m = mt * BM + row;
+            if (m > a.M - 1) m = a.M - 1;   // tail rows re-read the last pixel; their results are masked
+            const int b = m / a.HW;
+            const int rem = m - b * a.HW;
+            const int h = rem / a.W;
+            const int w = rem - h * a.W;
+            abase[it] = (long long)b * a.x_img_stride + (long long)h * a.x_row_stride + (long long)w * a.x_ld + a.x_off +
+                        (phys ^ swz<CPR>(row)) * 8;
+        }
+
+        f32x16_t acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        // Byte pointers of this thread's DMA pieces at chunk 0 (swizzle folded in); a chunk adds a wave-uniform
+        // offset: activations tap_off[tap] + channel offset, weights q * BK.
+        const char* aptr[A_IT];
+        const char* bptr[B_IT];
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) aptr[it] = (const char*)(a.x + abase[it]);
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) bptr[it] = (const char*)(a.w + bbase[it]);
+        // the next chunk to stage, in the packed K order [channel block of a.kb][tap][a.kb channels]:
+        // channel offset of its block, tap, offset inside the block, linear chunk index
+        int st_cb = 0, st_tap = 0, st_c = 0, st_q = 0;
+        auto stage_next = [&]() {
+            const int koff = (a.tap_off[st_tap] + st_cb + st_c) * 2;
+            const int woff = st_q * (BK * 2);
+            char* sa = smem + (st_q & (NST - 1)) * STAGE_BYTES;
+            char* sb = sa + A_SLOTS * 16;
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) glds16(aptr[it] + koff, sa + (it * NT + wave * 64) * 16);
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) glds16(bptr[it] + woff, sb + (it * NT + wave * 64) * 16);
+            ++st_q;
+            st_c += BK;
+            if (st_c == a.kb) {
+                st_c = 0;
+                if (++st_tap == a.ntaps) {
+                    st_tap = 0;
+                    st_cb += a.kb;
+                }
+            }
+        };
+        // Fragment addresses: row = tile row block + (lane & 31), so the swizzle term depends on the lane only and
+        // the k16 sub-step s flips bit 1 of the chunk index: two lane offsets per operand, constants for the rest.
+        const int lrow = lane & 31;
+        const int c0 = (lane >> 5) ^ swz<CPR>(lrow);
+        const int a_off0 = ((wm * WM + lrow) * CPR + c0) * 16, a_off1 = ((wm * WM + lrow) * CPR + (c0 ^ 2)) * 16;
+        const int b_off0 = A_SLOTS * 16 + ((wn * WN + lrow) * CPR + c0) * 16;
+        const int b_off1 = A_SLOTS * 16 + ((wn * WN + lrow) * CPR + (c0 ^ 2)) * 16;
+
+        __syncthreads();   // previous tile's epilogue is done with the LDS (and drained every DMA)
+#pragma unroll
+        for (int q = 0; q < NST - 1; ++q)
+            if (q < nchunks) stage_next();
+        // chunk 0 landed for every wave before anybody's phase 0
+        if (nchunks >= 3) wait_vm<2 * DPC>();
+        else if (nchunks == 2) wait_vm<DPC>();
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (group == 1) __builtin_amdgcn_s_barrier();   // the stagger: group 1 runs one episode behind
+
+        for (int p = 0; p < nchunks; ++p) {
+            // ---------------- memory phase: wait for chunk p+1, read the fragments of chunk p ----------------
+            __builtin_amdgcn_sched_barrier(0);   // nothing of this phase is scheduled above the barrier that opens it
+            if (DBG == 1) wait_vm<0>();
+            else if (p + 2 < nchunks) wait_vm<DPC>();   // chunk p+2 (issued in matrix phase p-1) may still be in flight
+            else wait_vm<0>();
+            const char* sbase = smem + (p & (NST - 1)) * STAGE_BYTES;
+            h8_t af[2][TM], bf[2][TN];
+            if (DBG == 2) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[s][j] = (h8_t)(half_t)(float)(p + j);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[s][i] = (h8_t)(half_t)(float)(p - i);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bf[0][j] = *(const h8_t*)(sbase + b_off0 + j * (32 * CPR * 16));
+                    bf[1][j] = *(const h8_t*)(sbase + b_off1 + j * (32 * CPR * 16));
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    af[0][i] = *(const h8_t*)(sbase + a_off0 + i * (32 * CPR * 16));
+                    af[1][i] = *(const h8_t*)(sbase + a_off1 + i * (32 * CPR * 16));
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired BEFORE the barrier (WAR rule above)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---------------- matrix phase: 16 MFMAs with the 4 DMA instructions of chunk p+3 between them ----------------
+            // (issued here, not in a burst at the start of the memory phase: every wave feeds the DMA path all the
+            // time and the issue cost hides behind this wave's own MFMAs)
+            const bool more = DBG != 1 && p + NST - 1 < nchunks;
+            const int koff = (a.tap_off[st_tap] + st_cb + st_c) * 2;
+            const int woff = st_q * (BK * 2);
+            char* sa = smem + (st_q & (NST - 1)) * STAGE_BYTES;
+            char* sb = sa + A_SLOTS * 16;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
+                        const int m = (s * TM + i) * TN + j;            // 0..15
+                        if (more && (m & 3) == 1) {
+                            const int piece = m >> 2;                    // 0..3: A0, A1, B0, B1
+                            if (piece < A_IT) glds16(aptr[piece] + koff, sa + (piece * NT + wave * 64) * 16);
+                            else glds16(bptr[piece - A_IT] + woff, sb + ((piece - A_IT) * NT + wave * 64) * 16);
+                        }
+                    }
+            __builtin_amdgcn_s_setprio(0);
+            if (more) {
+                ++st_q;
+                st_c += BK;
+                if (st_c == a.kb) {
+                    st_c = 0;
+                    if (++st_tap == a.ntaps) {
+                        st_tap = 0;
+                        st_cb += a.kb;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (group == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last barrier: both groups aligned again
+
+        // ------------------------------- epilogue (as conv_igemm.hip) -------------------------------
+        if constexpr (EPI == MCAMD_EPI_NCHW_F32) {
+            float* y = (float*)a.y;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mt * BM + wm * WM + i * 32 + mfma32_row(r, lane);
+                    if (m < a.M) {
+                        const int b = m / a.HW;
+                        const int hw = m - b * a.HW;
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const int n = nt * BN + wn * WN + j * 32 + (lane & 31);
+                            if (n < a.N) {
+                                float v = acc[i][j][r];
+                                if (a.bias) v += a.bias[n];
+                                y[((long long)b * a.N + n) * a.HW + hw] = v;
+                            }
+                        }
+                    }
+                }
+        } else {
+            __syncthreads();   // every wave is done with the stage buffers
+            half_t* ct = (half_t*)smem;   // [BM][BN] fp16 output tile (128 KB)
+            const int mlim = a.M - mt * BM;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = wn * WN + j * 32 + (lane & 31);
+                float sc = 1.f, sh = 0.f;
+                if constexpr (EPI == MCAMD_EPI_PAD_F16) {
+                    const int n = nt * BN + col;
+                    if (n < a.N) {
+                        if (a.scale) sc = a.scale[n];
+                        if (a.shift) sh = a.shift[n];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wm * WM + i * 32 + mfma32_row(r, lane);
+                        float v = acc[i][j][r];
+                        if constexpr (EPI == MCAMD_EPI_PAD_F16) {
+                            v = v * sc + sh;
+                            v = v > 0.f ? v : v * a.slope;
+                        }
+                        const half_t hv = (half_t)fminf(fmaxf(v, -65504.f), 65504.f);
+                        ct[row * BN + col] = hv;
+                        if (EPI == MCAMD_EPI_RAW_F16 && a.stats) {
+                            const float fv = (row < mlim) ? (float)hv : 0.f;
+                            s1[j] += fv;
+                            s2[j] += fv * fv;
+                        }
+                    }
+            }
+            __syncthreads();
+            constexpr int CH = BN / 8;
+            half_t* y = (half_t*)a.y;
+            for (int slot = tid; slot < BM * CH; slot += NT) {
+                const int row = slot / CH, ch = slot - row * CH;
+                const int m = mt * BM + row;
+                const int n0 = nt * BN + ch * 8;
+                if (m < a.M && n0 < a.N) {
+                    long long off;
+                    if constexpr (EPI == MCAMD_EPI_PAD_F16) {
+                        const int b = m / a.HW;
+                        const int rem = m - b * a.HW;
+                        const int h = rem / a.W;
+                        const int w = rem - h * a.W;
+                        off = (((long long)b * (a.H + 2) + h + 1) * (a.W + 2) + w + 1) * a.y_ld;
+                    } else {
+                        off = (long long)m * a.y_ld;
+                    }
+                    *(h8_t*)(y + off + a.y_choff + n0) = *(const h8_t*)(ct + row * BN + ch * 8);
+                }
+            }
+        }
+    }
+
+    if (EPI == MCAMD_EPI_RAW_F16 && a.stats) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            s1[j] += __shfl_xor(s1[j], 32);
+            s2[j] += __shfl_xor(s2[j], 32);
+        }
+        __syncthreads();
+        float* red = (float*)smem;   // [BM/WM][2][BN]
+        if (lane < 32) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                red[(wm * 2 + 0) * BN + wn * WN + j * 32 + lane] = s1[j];
+                red[(wm * 2 + 1) * BN + wn * WN + j * 32 + lane] = s2[j];
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < 2 * BN; t += NT) {
+            const int which = t / BN, col = t - which * BN;
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < BM / WM; ++k) v += red[(k * 2 + which) * BN + col];
+            a.stats[((long long)pslot * 2 + which) * a.stats_ld + nt * BN + col] = v;
+        }
+    }
+}
+
+template <int EPI, int DBG = 0>
+static void launch_pp(const IgemmArgs& a, int rows, int ntiles, hipStream_t st) {
+    const size_t lds = (size_t)NST * STAGE_BYTES;   // 128 KB: the ring, then the fp16 output tile
+    static_assert((size_t)BM * BN * 2 <= (size_t)NST * STAGE_BYTES, "output tile fits the ring");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)igemm_pp_kernel<EPI, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((igemm_pp_kernel<EPI, DBG>), dim3(round_up_int(rows, 8) * ntiles + 8), dim3(NT), lds, st, a);
+}
+
+// a.* filled as for mcamd_igemm_launch; needs N % 256 == 0 rows in the packed weights (they are padded to 256),
+// cin_tap % 32 == 0, at least one chunk.
+int mcamd_igemm_pp_launch(const IgemmArgs& a, int rows, int ntiles, hipStream_t st) {
+    if (a.cin_tap % BK != 0 || a.ktot < BK) {
+        mcamd_set_error("igemm_pp: K per tap (%d) must be a multiple of %d", a.cin_tap, BK);
+        return MCAMD_EINVAL;
+    }
+    static const int dbg = getenv("MCAMD_PP_DBG") ? atoi(getenv("MCAMD_PP_DBG")) : 0;
+    if (dbg == 1 && a.mode == MCAMD_EPI_RAW_F16) launch_pp<MCAMD_EPI_RAW_F16, 1>(a, rows, ntiles, st);
+    else if (dbg == 2 && a.mode == MCAMD_EPI_RAW_F16) launch_pp<MCAMD_EPI_RAW_F16, 2>(a, rows, ntiles, st);
+    else if (a.mode == MCAMD_EPI_NCHW_F32) launch_pp<MCAMD_EPI_NCHW_F32>(a, rows, ntiles, st);
+    else if (a.mode == MCAMD_EPI_PAD_F16) launch_pp<MCAMD_EPI_PAD_F16>(a, rows, ntiles, st);
+    else launch_pp<MCAMD_EPI_RAW_F16>(a, rows, ntiles, st);
+    MCAMD_LAUNCH_CHECK("igemm_pp");
+    return MCAMD_OK;
+}

@@ -18,6 +18,7 @@ struct IgemmArgs {
     int ktot;                // ntaps * cin_tap
     int cin_tap;
     int ntaps;
+    int kb;                  // channel-block size of the packed K order [cb][tap][kb]: 64 when cin_tap % 64 == 0, else 32
     int tap_off[9];          // element offset of tap t from the row base
     int mode;
     int y_ld, y_choff;
@@ -70,7 +71,8 @@ struct WgradPlan {
     size_t bytes;
 };
 
-void mcamd_igemm_tile(long long M, int n, int cin_tap, int ktot, int out[3]);
+void mcamd_igemm_tile(long long M, int n, int cin_tap, int ktot, int out[4]);   // {BM, BN, BK, kind}: kind 0 igemm_kernel, 2 igemm_pp_kernel
+int mcamd_igemm_pp_launch(const IgemmArgs& a, int rows, int ntiles, hipStream_t st);
 int mcamd_igemm_rows(long long M, int n, int cin_tap, int ktot);
 int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st);
 

@@ -205,6 +205,42 @@ def test_channel_maps_pack_fwd_dgrad_wgrad(dev, k, cin, cout_full, n_phys):
     assert rel_l2(y2.cpu(), F.conv2d(q16(x_phys), q16(w[rows]), None, 1, (k - 1) // 2)) < TOL
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout,k", [(4, 13, 13, 512, 1024, 3), (3, 26, 26, 256, 512, 3), (5, 20, 12, 1024, 256, 1),
+                                              (4, 9, 11, 96, 320, 3)])
+def test_pingpong_igemm_bit_identical_to_igemm(dev, monkeypatch, B, H, W, cin, cout, k):
+    """igemm_pp_kernel (256x256 ping-pong, conv_igemm_pp.hip) accumulates over K in the same order as
+    igemm_kernel, so raw fp16 outputs, BN partial sums and the fp32 dgrad are BIT-identical -- which also
+    screens the barrier/vmcnt ring for races: repeated launches must keep reproducing the same bits."""
+    gen = torch.Generator().manual_seed(51)
+    x = torch.rand(B, cin, H, W, generator=gen)
+    w = torch.randn(cout, cin, k, k, generator=gen) * (2.0 / (cin * k * k)) ** 0.5
+    gy = torch.randn(B, cout, H, W, generator=gen)
+    xb, ld = to_padded(x.to(dev))
+    dyb, dy_ld = to_padded(gy.to(dev))
+    g = ops.geom(B, H, W, k, cin, cout, ld)
+    wp, wd = ops.pack_weights(g, w.to(dev).contiguous())
+
+    def run():
+        y = torch.zeros(B * H * W * cout, dtype=torch.float16, device=dev)
+        stats = torch.zeros(ops.stats_rows(g), 2, ops.round_up(cout, 256), device=dev)
+        ops.conv_fwd_raw(g, xb, wp, y, cout, 0, stats)
+        dx = torch.zeros(B, cin, H, W, device=dev)
+        ops.conv_dgrad_nchw(g, dyb, dy_ld, 0, wd, dx)
+        return y, stats.sum(0), dx, ops.tile_info(g), ops.tile_info(g, dgrad=True)
+    monkeypatch.setenv("MCAMD_PP", "0")
+    y0, s0, dx0, t0, _ = run()
+    assert t0[3] == 0
+    monkeypatch.setenv("MCAMD_PP", "2")
+    for rep in range(6):
+        y1, s1, dx1, t1, t1d = run()
+        assert t1[3] == 2 and t1[:3] == (256, 256, 32) and t1d[3] == (2 if cin >= 128 else 0)
+        assert torch.equal(y1, y0), "forward differs (rep %d)" % rep
+        assert torch.equal(dx1, dx0), "dgrad differs (rep %d)" % rep
+        assert rel_l2(s1.cpu(), s0.cpu()) < 1e-6          # partial-sum rows are grouped differently (fp32 order)
+    yr = F.conv2d(q16(x), q16(w), None, 1, (k - 1) // 2)
+    assert rel_l2(raw_to_nchw(y1, B, H, W, cout, cout), yr) < TOL
+
+
 def test_pack_many_equals_per_layer_pack(dev):
     """mcamd_pack_weights_many (every layer in one launch) writes exactly what mcamd_pack_weights writes."""
     gen = torch.Generator().manual_seed(41)
