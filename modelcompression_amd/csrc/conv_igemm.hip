@@ -352,9 +352,16 @@ static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot) {
     t.kind = 0;
     // 256x256 ping-pong form (one workgroup per CU).  MCAMD_PP: 0 never, 1 by the cost rule below, 2 whenever legal.
     {
-        const int pp = env_int("MCAMD_PP", 0);
+        const int pp = env_int("MCAMD_PP", 1);
         if (pp && ktot >= 256 && n >= 128 && M >= 256) {
             bool use = pp == 2;
+            if (pp == 1 && n >= 256 && ktot >= 1024) {
+                // Measured (profiles/): per busy CU the ping-pong tile is ~1.27x the 192x128 tile, but
+                // it runs ONE workgroup per CU, so it only pays when its tiles fill the 256 CUs well.
+                const long long tiles = ((M + 255) / 256) * ((n + 255) / 256);
+                const double fill = (double)tiles / (double)(((tiles + 255) / 256) * 256);
+                use = fill >= 0.8;
+            }
             if (use) {
                 t.bm = 256, t.bn = 256, t.bk = 32, t.kind = 2;
                 return t;
