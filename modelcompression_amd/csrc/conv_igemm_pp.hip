@@ -13,7 +13,9 @@
 //                        chunk p, retire them (lgkmcnt 0)
 //         s_barrier
 //         matrix phase : 16 x v_mfma_f32_32x32x16_f16, with the 4 LDS-DMA instructions of chunk p+3
-//                        issued between them (all 8 waves feed the DMA path continuously)
+//                        issued between them (all 8 waves feed the DMA path continuously: 13-17 % faster
+//                        than a burst at the start of the memory phase; s_setprio and other placements
+//                        of the four instructions measured within 2 %)
 //         s_barrier
 //   * group 1 executes ONE extra s_barrier before its first phase (and group 0 one after its last), so
 //     the groups run half a chunk apart: while one group's waves multiply, the other group's waves on
@@ -56,10 +58,7 @@ __device__ __forceinline__ void wait_vm() {
 
 }  // namespace
 
-// DBG (timing experiments only, results are wrong): 1 = no DMA inside the K loop, 2 = no fragment reads
-// NMEM: how many of a chunk's 4 DMA instructions are issued in the memory phase (the rest between the MFMAs)
-// VAR (experiments): 1 = no s_setprio, 2 = DMA instructions before the MFMAs, 3 = after them, 4 = no prio + before
-template <int EPI, int DBG = 0, int NMEM = 0, int VAR = 0>
+template <int EPI>
 __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -162,7 +161,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
         for (int p = 0; p < nchunks; ++p) {
             // ---------------- memory phase: wait for chunk p+1, read the fragments of chunk p ----------------
             __builtin_amdgcn_sched_barrier(0);   // nothing of this phase is scheduled above the barrier that opens it
-            const bool more = DBG != 1 && p + NST - 1 < nchunks;
+            const bool more = p + NST - 1 < nchunks;
             const int koff = (a.tap_off[st_tap] + st_cb + st_c) * 2;
             const int woff = st_q * (BK * 2);
             char* sa = smem + (st_q & (NST - 1)) * STAGE_BYTES;
@@ -171,36 +170,20 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
                 if (piece < A_IT) glds16(aptr[piece] + koff, sa + (piece * NT + wave * 64) * 16);
                 else glds16(bptr[piece - A_IT] + woff, sb + ((piece - A_IT) * NT + wave * 64) * 16);
             };
-            if (more) {
-#pragma unroll
-                for (int piece = 0; piece < NMEM; ++piece) issue_piece(piece);
-            }
-            // chunk p+1 must have landed; younger pieces (chunk p+2, the NMEM just issued) may stay in flight
-            if (DBG == 1) wait_vm<0>();
-            else if (more) wait_vm<DPC + NMEM>();
-            else if (p + 2 < nchunks) wait_vm<DPC>();
+            // chunk p+1 must have landed; chunk p+2 (issued in matrix phase p-1) may still be in flight
+            if (p + 2 < nchunks) wait_vm<DPC>();
             else wait_vm<0>();
             const char* sbase = smem + (p & (NST - 1)) * STAGE_BYTES;
             h8_t af[2][TM], bf[2][TN];
-            if (DBG == 2) {
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
+            for (int j = 0; j < TN; ++j) {
+                bf[0][j] = *(const h8_t*)(sbase + b_off0 + j * (32 * CPR * 16));
+                bf[1][j] = *(const h8_t*)(sbase + b_off1 + j * (32 * CPR * 16));
+            }
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) bf[s][j] = (h8_t)(half_t)(float)(p + j);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) af[s][i] = (h8_t)(half_t)(float)(p - i);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    bf[0][j] = *(const h8_t*)(sbase + b_off0 + j * (32 * CPR * 16));
-                    bf[1][j] = *(const h8_t*)(sbase + b_off1 + j * (32 * CPR * 16));
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    af[0][i] = *(const h8_t*)(sbase + a_off0 + i * (32 * CPR * 16));
-                    af[1][i] = *(const h8_t*)(sbase + a_off1 + i * (32 * CPR * 16));
-                }
+            for (int i = 0; i < TM; ++i) {
+                af[0][i] = *(const h8_t*)(sbase + a_off0 + i * (32 * CPR * 16));
+                af[1][i] = *(const h8_t*)(sbase + a_off1 + i * (32 * CPR * 16));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired BEFORE the barrier (WAR rule above)
             __builtin_amdgcn_sched_barrier(0);
@@ -209,11 +192,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
             // ---------------- matrix phase: 16 MFMAs with the 4 DMA instructions of chunk p+3 between them ----------------
             // (issued here, not in a burst at the start of the memory phase: every wave feeds the DMA path all the
             // time and the issue cost hides behind this wave's own MFMAs)
-            if ((VAR == 2 || VAR == 4) && more) {
-#pragma unroll
-                for (int piece = NMEM; piece < DPC; ++piece) issue_piece(piece);
-            }
-            if (VAR != 1 && VAR != 4) __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -222,13 +201,9 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
                     for (int j = 0; j < TN; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
                         const int m = (s * TM + i) * TN + j;            // 0..15
-                        if (VAR < 2 && more && (m & 3) == 1 && (m >> 2) >= NMEM) issue_piece(m >> 2);
+                        if (more && (m & 3) == 1) issue_piece(m >> 2);
                     }
-            if (VAR != 1 && VAR != 4) __builtin_amdgcn_s_setprio(0);
-            if (VAR == 3 && more) {
-#pragma unroll
-                for (int piece = NMEM; piece < DPC; ++piece) issue_piece(piece);
-            }
+            __builtin_amdgcn_s_setprio(0);
             if (more) {
                 ++st_q;
                 st_c += BK;
@@ -351,16 +326,16 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
     }
 }
 
-template <int EPI, int DBG = 0, int NMEM = 0, int VAR = 0>
+template <int EPI>
 static void launch_pp(const IgemmArgs& a, int rows, int ntiles, hipStream_t st) {
     const size_t lds = (size_t)NST * STAGE_BYTES;   // 128 KB: the ring, then the fp16 output tile
     static_assert((size_t)BM * BN * 2 <= (size_t)NST * STAGE_BYTES, "output tile fits the ring");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_pp_kernel<EPI, DBG, NMEM, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((igemm_pp_kernel<EPI, DBG, NMEM, VAR>), dim3(round_up_int(rows, 8) * ntiles + 8), dim3(NT), lds, st, a);
+    hipLaunchKernelGGL((igemm_pp_kernel<EPI>), dim3(round_up_int(rows, 8) * ntiles + 8), dim3(NT), lds, st, a);
 }
 
 // a.* filled as for mcamd_igemm_launch; needs N % 256 == 0 rows in the packed weights (they are padded to 256),
@@ -370,17 +345,7 @@ int mcamd_igemm_pp_launch(const IgemmArgs& a, int rows, int ntiles, hipStream_t 
         mcamd_set_error("igemm_pp: K per tap (%d) must be a multiple of %d", a.cin_tap, BK);
         return MCAMD_EINVAL;
     }
-    static const int dbg = getenv("MCAMD_PP_DBG") ? atoi(getenv("MCAMD_PP_DBG")) : 0;
-    static const int nmem = getenv("MCAMD_PP_NMEM") ? atoi(getenv("MCAMD_PP_NMEM")) : 0;
-    static const int var = getenv("MCAMD_PP_VAR") ? atoi(getenv("MCAMD_PP_VAR")) : 0;
-    if (var == 1 && a.mode == MCAMD_EPI_RAW_F16) launch_pp<MCAMD_EPI_RAW_F16, 0, 0, 1>(a, rows, ntiles, st);
-    else if (var == 2 && a.mode == MCAMD_EPI_RAW_F16) launch_pp<MCAMD_EPI_RAW_F16, 0, 0, 2>(a, rows, ntiles, st);
-    else if (var == 3 && a.mode == MCAMD_EPI_RAW_F16) launch_pp<MCAMD_EPI_RAW_F16, 0, 0, 3>(a, rows, ntiles, st);
-    else if (var == 4 && a.mode == MCAMD_EPI_RAW_F16) launch_pp<MCAMD_EPI_RAW_F16, 0, 0, 4>(a, rows, ntiles, st);
-    else if (nmem == 1 && a.mode == MCAMD_EPI_RAW_F16) launch_pp<MCAMD_EPI_RAW_F16, 0, 1>(a, rows, ntiles, st);
-    else if (dbg == 1 && a.mode == MCAMD_EPI_RAW_F16) launch_pp<MCAMD_EPI_RAW_F16, 1>(a, rows, ntiles, st);
-    else if (dbg == 2 && a.mode == MCAMD_EPI_RAW_F16) launch_pp<MCAMD_EPI_RAW_F16, 2>(a, rows, ntiles, st);
-    else if (a.mode == MCAMD_EPI_NCHW_F32) launch_pp<MCAMD_EPI_NCHW_F32>(a, rows, ntiles, st);
+    if (a.mode == MCAMD_EPI_NCHW_F32) launch_pp<MCAMD_EPI_NCHW_F32>(a, rows, ntiles, st);
     else if (a.mode == MCAMD_EPI_PAD_F16) launch_pp<MCAMD_EPI_PAD_F16>(a, rows, ntiles, st);
     else launch_pp<MCAMD_EPI_RAW_F16>(a, rows, ntiles, st);
     MCAMD_LAUNCH_CHECK("igemm_pp");
