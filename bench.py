@@ -6,8 +6,9 @@
 One step = model(x) -> sum-of-logits loss -> backward (HIP engine) -> [gradient all-reduce]
 -> torch.optim.SGD step (lr 1e-5, momentum .9, weight_decay .0005*B: reference train.py:144-147)
 on one resident synthetic batch of B=64 images per GPU (BASELINE.json configs[1]).
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, the 128x128 implicit-GEMM
-MFMA convolution (forward + dgrad launches), timed live with HIP events on the launch stream;
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel: the implicit-GEMM MFMA convolution
+instance (forward + dgrad launches) with the largest total time in the timed region, every launch timed
+live with HIP events on the launch stream;
 `cpu_baseline` is the oracle (PyTorch-CPU restatement of the reference) on the host cores.
 """
 import argparse
@@ -173,7 +174,7 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         assert bool((lo == hi).all()), "ranks diverged: gradient / weight checksums differ (%s vs %s)" % (lo.tolist(), hi.tolist())
 
-    # ---- roofline of the dominant kernel: igemm_kernel<128,128,64,64,BK> (fwd + dgrad launches)
+    # ---- roofline of the dominant kernel: the igemm instance (fwd + dgrad launches) with the largest total time
     per = {}
     for tag, lay, e0, e1 in events:
         ms = e0.elapsed_time(e1)
