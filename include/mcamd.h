@@ -118,21 +118,23 @@ int mcamd_pack_weights(const mcamd_conv_geom* g, const float* w_oihw, const floa
                        const mcamd_chan_map* map, void* wp_fwd, void* wp_dgrad, void* stream);
 
 /* All layers of a network in ONE launch (the per-step re-pack of engine.py): `jobs_dev` is a DEVICE array of
- * `njobs` descriptors, one per destination (a layer has two: forward and dgrad layout).  An item is one
- * physical (filter n, input channel c) pair: its k*k taps are read as one contiguous run and written to
- * their k*k slots.  Only real entries are written -- pad rows / pad channels of `dst` must already be zero
+ * `njobs` descriptors, one per layer.  A workgroup takes a 32-filter x 32-channel tile of one layer: the
+ * k*k taps of every (filter, channel) pair are read as one contiguous run (x mask), transposed through LDS
+ * and written to BOTH packed layouts in 64-byte pieces, so the fp32 master and the mask are read once.
+ * Only real entries are written -- pad rows / pad channels of the destinations must already be zero
  * (they never change).  The stem layer is not supported here (use mcamd_pack_weights). */
 typedef struct mcamd_pack_job {
     const float* w;            /* OIHW fp32 master */
     const float* mask;         /* OIHW fp32 or NULL */
-    void* dst;                 /* fp16, forward layout (dgrad == 0) or dgrad layout (dgrad != 0) */
+    void* dst_fwd;             /* fp16 forward layout, or NULL */
+    void* dst_dgrad;           /* fp16 dgrad layout, or NULL */
     const int32_t* rows;       /* channel maps as in mcamd_chan_map, or NULL */
     const int32_t* cols;
-    int64_t first_item;        /* sum of cout*cin over the preceding jobs */
+    int64_t first_tile;        /* sum of ceil(cout/32)*ceil(cin/32) over the preceding jobs */
     int32_t cout, cin, ksize;  /* physical geometry */
-    int32_t dgrad;
+    int32_t reserved;
 } mcamd_pack_job;
-int mcamd_pack_weights_many(const mcamd_pack_job* jobs_dev, int32_t njobs, int64_t total_items, void* stream);
+int mcamd_pack_weights_many(const mcamd_pack_job* jobs_dev, int32_t njobs, int64_t total_tiles, void* stream);
 
 /* y = conv(x, w) -- replaces F.conv2d at layers.py:60-64. */
 int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const void* wp_fwd,

@@ -41,9 +41,10 @@ class ChanMap(C.Structure):
 
 
 class PackJob(C.Structure):
-    _fields_ = [("w", C.c_void_p), ("mask", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_void_p), ("cols", C.c_void_p),
-                ("first_item", C.c_int64), ("cout", C.c_int32), ("cin", C.c_int32), ("ksize", C.c_int32),
-                ("dgrad", C.c_int32)]
+    _fields_ = [("w", C.c_void_p), ("mask", C.c_void_p), ("dst_fwd", C.c_void_p), ("dst_dgrad", C.c_void_p),
+                ("rows", C.c_void_p), ("cols", C.c_void_p),
+                ("first_tile", C.c_int64), ("cout", C.c_int32), ("cin", C.c_int32), ("ksize", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class ActBwdDesc(C.Structure):

@@ -164,56 +164,73 @@ extern "C" int mcamd_pack_weights(const mcamd_conv_geom* g, const float* w_oihw,
     return MCAMD_OK;
 }
 
-// All layers in one launch.  item = (n, c) of one job; lanes run over c (forward layout) or n (dgrad layout) so
-// that the k*k fp16 stores of a wave are contiguous, and each lane reads its k*k taps as one 36-byte run.
-__global__ __launch_bounds__(256) void pack_many_kernel(const mcamd_pack_job* jobs, int njobs, long long total) {
-    for (long long item = (long long)blockIdx.x * 256 + threadIdx.x; item < total; item += (long long)gridDim.x * 256) {
-        int lo = 0, hi = njobs - 1;          // last job whose first_item <= item
+// All layers in one launch: a workgroup packs a 32-filter x 32-channel tile of one layer into both layouts.
+__global__ __launch_bounds__(256) void pack_tiles_kernel(const mcamd_pack_job* jobs, int njobs, long long total) {
+    constexpr int TS = 32, LDW = TS * 9 + 1;           // row stride of the LDS tile (odd: column reads spread over banks)
+    __shared__ float tile[TS * LDW];                    // [n][c * kk + t], 37 KB
+    for (long long item = blockIdx.x; item < total; item += gridDim.x) {
+        int lo = 0, hi = njobs - 1;                     // last job whose first_tile <= item
         while (lo < hi) {
             int mid = (lo + hi + 1) >> 1;
-            if (jobs[mid].first_item <= item) lo = mid;
+            if (jobs[mid].first_tile <= item) lo = mid;
             else hi = mid - 1;
         }
         const mcamd_pack_job j = jobs[lo];
-        const long long r = item - j.first_item;
-        int n, c;
-        if (j.dgrad) {
-            c = (int)(r / j.cout);
-            n = (int)(r - (long long)c * j.cout);
-        } else {
-            n = (int)(r / j.cin);
-            c = (int)(r - (long long)n * j.cin);
-        }
         const int ks = j.ksize, kk = ks * ks;
-        const int ns = j.rows ? j.rows[n] : n, cs = j.cols ? j.cols[c] : c;
-        const long long src = ((long long)ns * j.cin + cs) * kk;
-        half_t* dst = (half_t*)j.dst;
-        if (j.dgrad) {
-            const int cout_p = round_up_dev(j.cout, 32);
-            const long long base = (long long)c * kk * cout_p;
-            for (int t = 0; t < kk; ++t) {   // flipped taps
-                float v = j.w[src + kk - 1 - t];
-                if (j.mask) v *= j.mask[src + kk - 1 - t];
-                dst[base + kpos(t, n, kk, cout_p)] = (half_t)v;
+        const int ctiles = (j.cin + TS - 1) / TS;
+        const int r = (int)(item - j.first_tile);
+        const int n0 = (r / ctiles) * TS, c0 = (r - (r / ctiles) * ctiles) * TS;
+        __syncthreads();                                // the previous item's readers are done with the tile
+        // 1. gather: thread -> (n, c) pairs, c fastest: the k*k taps of a pair are one contiguous run
+        for (int pair = threadIdx.x; pair < TS * TS; pair += 256) {
+            const int nl = pair / TS, cl = pair - nl * TS;
+            const int n = n0 + nl, c = c0 + cl;
+            float v[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) v[t] = 0.f;
+            if (n < j.cout && c < j.cin) {
+                const int ns = j.rows ? j.rows[n] : n, cs = j.cols ? j.cols[c] : c;
+                const long long src = ((long long)ns * j.cin + cs) * kk;
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    if (t < kk) v[t] = j.mask ? j.w[src + t] * j.mask[src + t] : j.w[src + t];
             }
-        } else {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                if (t < kk) tile[nl * LDW + cl * kk + t] = v[t];
+        }
+        __syncthreads();
+        // 2. forward layout [n][kpos(t, c)]: 32 consecutive channels of one (filter, tap) = 64 contiguous bytes
+        if (j.dst_fwd) {
+            half_t* dst = (half_t*)j.dst_fwd;
             const int cin_tap = round_up_dev(j.cin, 32);
-            const long long base = (long long)n * kk * cin_tap;
-            for (int t = 0; t < kk; ++t) {
-                float v = j.w[src + t];
-                if (j.mask) v *= j.mask[src + t];
-                dst[base + kpos(t, c, kk, cin_tap)] = (half_t)v;
+            for (int e = threadIdx.x; e < TS * kk * TS; e += 256) {
+                const int cl = e % TS, t = (e / TS) % kk, nl = e / (TS * kk);
+                const int n = n0 + nl, c = c0 + cl;
+                if (n < j.cout && c < j.cin)
+                    dst[(long long)n * kk * cin_tap + kpos(t, c, kk, cin_tap)] = (half_t)tile[nl * LDW + cl * kk + t];
+            }
+        }
+        // 3. dgrad layout [c][kpos(t', n)], flipped taps: 32 consecutive filters of one (channel, tap) = 64 bytes
+        if (j.dst_dgrad) {
+            half_t* dst = (half_t*)j.dst_dgrad;
+            const int cout_p = round_up_dev(j.cout, 32);
+            for (int e = threadIdx.x; e < TS * kk * TS; e += 256) {
+                const int nl = e % TS, t = (e / TS) % kk, cl = e / (TS * kk);
+                const int n = n0 + nl, c = c0 + cl;
+                if (n < j.cout && c < j.cin)
+                    dst[(long long)c * kk * cout_p + kpos(t, n, kk, cout_p)] = (half_t)tile[nl * LDW + cl * kk + (kk - 1 - t)];
             }
         }
     }
 }
 
-extern "C" int mcamd_pack_weights_many(const mcamd_pack_job* jobs_dev, int32_t njobs, int64_t total_items, void* stream) {
-    MCAMD_REQUIRE(jobs_dev && njobs > 0 && total_items > 0, "pack_weights_many: empty job table");
-    long long grid = (total_items + 255) / 256;
-    if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(pack_many_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs,
-                       (long long)total_items);
+extern "C" int mcamd_pack_weights_many(const mcamd_pack_job* jobs_dev, int32_t njobs, int64_t total_tiles, void* stream) {
+    MCAMD_REQUIRE(jobs_dev && njobs > 0 && total_tiles > 0, "pack_weights_many: empty job table");
+    long long grid = total_tiles;
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(pack_tiles_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs,
+                       (long long)total_tiles);
     MCAMD_LAUNCH_CHECK("pack_weights_many");
     return MCAMD_OK;
 }

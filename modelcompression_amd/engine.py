@@ -346,10 +346,8 @@ class Engine:
                 if lay.stem:
                     continue
                 self._pack_keep += [w, mask]
-                common = dict(w=w, mask=mask, rows=lay.g_rows, cols=lay.g_cols, cout=lay.n_act, cin=lay.cin, ksize=lay.k)
-                jobs.append(dict(common, dst=lay.wp, dgrad=False))
-                if lay.wd is not None:
-                    jobs.append(dict(common, dst=lay.wd, dgrad=True))
+                jobs.append(dict(w=w, mask=mask, rows=lay.g_rows, cols=lay.g_cols, cout=lay.n_act, cin=lay.cin, ksize=lay.k,
+                                 dst_fwd=lay.wp, dst_dgrad=lay.wd))
             self._pack_table = ops.pack_table(jobs, self.device) if jobs else None
             self._pack_key = tkey
         for lay in self.layers:

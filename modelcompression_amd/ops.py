@@ -83,25 +83,26 @@ def pack_weights(g, w, mask=None, want_fwd=True, want_dgrad=True, out_fwd=None, 
 
 
 def pack_table(jobs, device):
-    """jobs: list of dicts(w, mask, dst, rows, cols, cout, cin, ksize, dgrad) -> (device table, njobs, total items)
-    for `pack_many` (mcamd_pack_job array).  The tensors must stay alive and in place while the table is used."""
+    """jobs: list of dicts(w, mask, dst_fwd, dst_dgrad, rows, cols, cout, cin, ksize), one per layer ->
+    (device table, njobs, total tiles) for `pack_many` (mcamd_pack_job array).  The tensors must stay alive and
+    in place while the table is used."""
     arr = (PackJob * len(jobs))()
     total = 0
     for a, j in zip(arr, jobs):
-        _need_cuda(j["w"], j["dst"])
-        assert j["w"].dtype == torch.float32 and j["w"].is_contiguous() and j["dst"].dtype == HALF
-        a.w, a.dst = j["w"].data_ptr(), j["dst"].data_ptr()
-        a.mask = j["mask"].data_ptr() if j.get("mask") is not None else None
-        a.rows = j["rows"].data_ptr() if j.get("rows") is not None else None
-        a.cols = j["cols"].data_ptr() if j.get("cols") is not None else None
-        a.first_item, a.cout, a.cin, a.ksize, a.dgrad = total, j["cout"], j["cin"], j["ksize"], 1 if j["dgrad"] else 0
-        total += j["cout"] * j["cin"]
+        _need_cuda(j["w"], j.get("dst_fwd"), j.get("dst_dgrad"))
+        assert j["w"].dtype == torch.float32 and j["w"].is_contiguous()
+        a.w = j["w"].data_ptr()
+        for name in ("mask", "dst_fwd", "dst_dgrad", "rows", "cols"):
+            setattr(a, name, j[name].data_ptr() if j.get(name) is not None else None)
+        a.first_tile, a.cout, a.cin, a.ksize = total, j["cout"], j["cin"], j["ksize"]
+        total += ((j["cout"] + 31) // 32) * ((j["cin"] + 31) // 32)
     host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
     return host.to(device), len(jobs), total
 
 
 def pack_many(table, njobs, total):
-    """Every (non-stem) layer's fwd + dgrad packing in one launch; pads of the destinations must already be zero."""
+    """Every (non-stem) layer's forward + dgrad packing in one launch (the master and the mask are read once);
+    pads of the destinations must already be zero."""
     check(L.lib().mcamd_pack_weights_many(ptr(table), njobs, total, stream_ptr()), "mcamd_pack_weights_many")
 
 

@@ -258,12 +258,16 @@ def test_pack_many_equals_per_layer_pack(dev):
         want += [wp, wd]
         mine = [torch.zeros_like(wp), torch.zeros_like(wd)]
         keep += [w, mask, rows, cols] + mine
-        for dst, dg in zip(mine, (False, True)):
-            jobs.append(dict(w=w, mask=mask, rows=rows, cols=cols, cout=cout, cin=cin, ksize=k, dst=dst, dgrad=dg))
+        jobs.append(dict(w=w, mask=mask, rows=rows, cols=cols, cout=cout, cin=cin, ksize=k, dst_fwd=mine[0], dst_dgrad=mine[1]))
     table = ops.pack_table(jobs, dev)
     ops.pack_many(*table)
-    for j, ref in zip(jobs, want):
-        assert torch.equal(j["dst"], ref), (j["cout"], j["cin"], j["ksize"], j["dgrad"])
+    for idx, j in enumerate(jobs):
+        assert torch.equal(j["dst_fwd"], want[2 * idx]), (j["cout"], j["cin"], j["ksize"], "fwd")
+        assert torch.equal(j["dst_dgrad"], want[2 * idx + 1]), (j["cout"], j["cin"], j["ksize"], "dgrad")
+    # forward-only job (the first conv after the stem has no dgrad consumer in some plans)
+    only = torch.zeros_like(want[0])
+    ops.pack_many(*ops.pack_table([dict(jobs[0], dst_fwd=only, dst_dgrad=None)], dev))
+    assert torch.equal(only, want[0])
 
 
 def test_wgrad_stem(dev):
