@@ -41,15 +41,12 @@
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 32, NST = 4;
-constexpr int WM = 128, WN = 64, WAVES_N = BN / WN;          // 2 x 4 waves
+constexpr int BN = 256, BK = 32, NST = 4;
+constexpr int WN = 64, WAVES_N = BN / WN;                     // 2 (M) x 4 (N) waves
 constexpr int NT = 512;
 constexpr int CPR = BK / 8;                                   // 16-byte chunks per LDS row (64-byte rows)
-constexpr int A_SLOTS = BM * CPR, B_SLOTS = BN * CPR;
-constexpr int A_IT = A_SLOTS / NT, B_IT = B_SLOTS / NT;       // 2 + 2 DMA instructions per wave per chunk
-constexpr int DPC = A_IT + B_IT;
-constexpr int TM = WM / 32, TN = WN / 32;                     // 4 x 2 accumulator blocks
-constexpr int STAGE_BYTES = (A_SLOTS + B_SLOTS) * 16;         // 32 KB
+constexpr int B_SLOTS = BN * CPR, B_IT = B_SLOTS / NT;
+constexpr int TN = WN / 32;
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -58,13 +55,35 @@ __device__ __forceinline__ void wait_vm() {
 
 }  // namespace
 
-template <int EPI>
+// BM = 256 (wave tile 128x64) or 192 (wave tile 96x64: 228 tiles instead of 172 for the 13x13 layers at B=64).
+// With BM = 192 the A tile is 1.5 DMA instructions per thread: waves 0-3 (= group 0) issue two A pieces, waves 4-7
+// one, so the counted waits differ per group.
+template <int EPI, int BM>
 __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
+    constexpr int WM = BM / 2, TM = WM / 32;
+    constexpr int A_SLOTS = BM * CPR;
+    constexpr int A_IT = (A_SLOTS + NT - 1) / NT;             // 2 (the second one only for waves 0-3 when BM = 192)
+    constexpr bool RAGGED = A_SLOTS % NT != 0;
+    constexpr int DPC = A_IT + B_IT;                          // DMA instructions per chunk of waves 0-3
+    constexpr int STAGE_BYTES = (A_SLOTS + B_SLOTS) * 16;     // 32 KB / 28 KB
+    static_assert(BM == 256 || BM == 192, "wave tiles of 128 or 96 rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int group = wave >> 2;   // waves 0-3 / 4-7: one of each per SIMD
+    // counted waits: "at most n chunks' worth of this wave's DMA instructions still in flight"
+    auto wait_chunks = [&](int n) {
+        if (RAGGED && group == 1) {
+            if (n == 2) wait_vm<2 * (DPC - 1)>();
+            else if (n == 1) wait_vm<DPC - 1>();
+            else wait_vm<0>();
+        } else {
+            if (n == 2) wait_vm<2 * DPC>();
+            else if (n == 1) wait_vm<DPC>();
+            else wait_vm<0>();
+        }
+    };
 
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int nt = jb % a.num_ntiles;
@@ -90,7 +109,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int slot = it * NT + tid;
-            const int row = slot / CPR, phys = slot % CPR;
+            const int row = (slot / CPR) % BM, phys = slot % CPR;   // (slots beyond the tile, BM = 192: never issued)
             int m = mt * BM + row;
             if (m > a.M - 1) m = a.M - 1;   // tail rows re-read the last pixel; their results are masked
             const int b = m / a.HW;
@@ -126,7 +145,8 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
             char* sa = smem + (st_q & (NST - 1)) * STAGE_BYTES;
             char* sb = sa + A_SLOTS * 16;
 #pragma unroll
-            for (int it = 0; it < A_IT; ++it) glds16(aptr[it] + koff, sa + (it * NT + wave * 64) * 16);
+            for (int it = 0; it < A_IT; ++it)
+                if (it * NT + wave * 64 < A_SLOTS) glds16(aptr[it] + koff, sa + (it * NT + wave * 64) * 16);
 #pragma unroll
             for (int it = 0; it < B_IT; ++it) glds16(bptr[it] + woff, sb + (it * NT + wave * 64) * 16);
             ++st_q;
@@ -152,9 +172,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
         for (int q = 0; q < NST - 1; ++q)
             if (q < nchunks) stage_next();
         // chunk 0 landed for every wave before anybody's phase 0
-        if (nchunks >= 3) wait_vm<2 * DPC>();
-        else if (nchunks == 2) wait_vm<DPC>();
-        else wait_vm<0>();
+        wait_chunks(nchunks >= 3 ? 2 : nchunks - 1);
         __builtin_amdgcn_s_barrier();
         if (group == 1) __builtin_amdgcn_s_barrier();   // the stagger: group 1 runs one episode behind
 
@@ -167,12 +185,14 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
             char* sa = smem + (st_q & (NST - 1)) * STAGE_BYTES;
             char* sb = sa + A_SLOTS * 16;
             auto issue_piece = [&](int piece) {   // 0..3: A0, A1, B0, B1 of chunk p+3
-                if (piece < A_IT) glds16(aptr[piece] + koff, sa + (piece * NT + wave * 64) * 16);
-                else glds16(bptr[piece - A_IT] + woff, sb + ((piece - A_IT) * NT + wave * 64) * 16);
+                if (piece < A_IT) {
+                    if (piece * NT + wave * 64 < A_SLOTS) glds16(aptr[piece] + koff, sa + (piece * NT + wave * 64) * 16);
+                } else {
+                    glds16(bptr[piece - A_IT] + woff, sb + ((piece - A_IT) * NT + wave * 64) * 16);
+                }
             };
             // chunk p+1 must have landed; chunk p+2 (issued in matrix phase p-1) may still be in flight
-            if (p + 2 < nchunks) wait_vm<DPC>();
-            else wait_vm<0>();
+            wait_chunks(p + 2 < nchunks ? 1 : 0);
             const char* sbase = smem + (p & (NST - 1)) * STAGE_BYTES;
             h8_t af[2][TM], bf[2][TN];
 #pragma unroll
@@ -200,8 +220,9 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
-                        const int m = (s * TM + i) * TN + j;            // 0..15
-                        if (more && (m & 3) == 1) issue_piece(m >> 2);
+                        const int m = (s * TM + i) * TN + j;            // 0..15 (0..11 for BM = 192)
+                        constexpr int EVERY = 2 * TM * TN / 4;          // one DMA instruction per EVERY MFMAs
+                        if (more && m % EVERY == 1) issue_piece(m / EVERY);
                     }
             __builtin_amdgcn_s_setprio(0);
             if (more) {
@@ -326,28 +347,34 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
     }
 }
 
-template <int EPI>
+template <int EPI, int BM>
 static void launch_pp(const IgemmArgs& a, int rows, int ntiles, hipStream_t st) {
-    const size_t lds = (size_t)NST * STAGE_BYTES;   // 128 KB: the ring, then the fp16 output tile
-    static_assert((size_t)BM * BN * 2 <= (size_t)NST * STAGE_BYTES, "output tile fits the ring");
+    constexpr size_t ring = (size_t)NST * (BM * CPR + B_SLOTS) * 16;   // 128 KB / 112 KB: the ring, then the fp16 output tile
+    static_assert((size_t)BM * BN * 2 <= ring, "output tile fits the ring");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm_pp_kernel<EPI, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring);
         attr_set = true;
     }
-    hipLaunchKernelGGL((igemm_pp_kernel<EPI>), dim3(round_up_int(rows, 8) * ntiles + 8), dim3(NT), lds, st, a);
+    hipLaunchKernelGGL((igemm_pp_kernel<EPI, BM>), dim3(round_up_int(rows, 8) * ntiles + 8), dim3(NT), ring, st, a);
 }
 
 // a.* filled as for mcamd_igemm_launch; needs N % 256 == 0 rows in the packed weights (they are padded to 256),
-// cin_tap % 32 == 0, at least one chunk.
-int mcamd_igemm_pp_launch(const IgemmArgs& a, int rows, int ntiles, hipStream_t st) {
-    if (a.cin_tap % BK != 0 || a.ktot < BK) {
-        mcamd_set_error("igemm_pp: K per tap (%d) must be a multiple of %d", a.cin_tap, BK);
+// cin_tap % 32 == 0, at least one chunk.  bm = 256 or 192.
+int mcamd_igemm_pp_launch(const IgemmArgs& a, int bm, int rows, int ntiles, hipStream_t st) {
+    if (a.cin_tap % BK != 0 || a.ktot < BK || a.kb % BK != 0 || (bm != 256 && bm != 192)) {
+        mcamd_set_error("igemm_pp: K per tap (%d) must be a multiple of %d, BM (%d) 256 or 192", a.cin_tap, BK, bm);
         return MCAMD_EINVAL;
     }
-    if (a.mode == MCAMD_EPI_NCHW_F32) launch_pp<MCAMD_EPI_NCHW_F32>(a, rows, ntiles, st);
-    else if (a.mode == MCAMD_EPI_PAD_F16) launch_pp<MCAMD_EPI_PAD_F16>(a, rows, ntiles, st);
-    else launch_pp<MCAMD_EPI_RAW_F16>(a, rows, ntiles, st);
+#define PP_CASE(EPI_)                                                  \
+    do {                                                               \
+        if (bm == 256) launch_pp<EPI_, 256>(a, rows, ntiles, st);      \
+        else launch_pp<EPI_, 192>(a, rows, ntiles, st);                \
+    } while (0)
+    if (a.mode == MCAMD_EPI_NCHW_F32) PP_CASE(MCAMD_EPI_NCHW_F32);
+    else if (a.mode == MCAMD_EPI_PAD_F16) PP_CASE(MCAMD_EPI_PAD_F16);
+    else PP_CASE(MCAMD_EPI_RAW_F16);
+#undef PP_CASE
     MCAMD_LAUNCH_CHECK("igemm_pp");
     return MCAMD_OK;
 }

@@ -205,9 +205,10 @@ def test_channel_maps_pack_fwd_dgrad_wgrad(dev, k, cin, cout_full, n_phys):
     assert rel_l2(y2.cpu(), F.conv2d(q16(x_phys), q16(w[rows]), None, 1, (k - 1) // 2)) < TOL
 
 
+@pytest.mark.parametrize("bm", [256, 192])
 @pytest.mark.parametrize("B,H,W,cin,cout,k", [(4, 13, 13, 512, 1024, 3), (3, 26, 26, 256, 512, 3), (5, 20, 12, 1024, 256, 1),
                                               (4, 9, 11, 96, 320, 3)])
-def test_pingpong_igemm_bit_identical_to_igemm(dev, monkeypatch, B, H, W, cin, cout, k):
+def test_pingpong_igemm_bit_identical_to_igemm(dev, monkeypatch, bm, B, H, W, cin, cout, k):
     """igemm_pp_kernel (256x256 ping-pong, conv_igemm_pp.hip) accumulates over K in the same order as
     igemm_kernel, so raw fp16 outputs, BN partial sums and the fp32 dgrad are BIT-identical -- which also
     screens the barrier/vmcnt ring for races: repeated launches must keep reproducing the same bits."""
@@ -231,9 +232,10 @@ def test_pingpong_igemm_bit_identical_to_igemm(dev, monkeypatch, B, H, W, cin, c
     y0, s0, dx0, t0, _ = run()
     assert t0[3] == 0
     monkeypatch.setenv("MCAMD_PP", "2")
+    monkeypatch.setenv("MCAMD_PP_BM", str(bm))
     for rep in range(6):
         y1, s1, dx1, t1, t1d = run()
-        assert t1[3] == 2 and t1[:3] == (256, 256, 32) and t1d[3] == (2 if cin >= 128 else 0)
+        assert t1[3] == 2 and t1[:3] == (bm, 256, 32) and t1d[3] == (2 if cin >= 128 else 0)
         assert torch.equal(y1, y0), "forward differs (rep %d)" % rep
         assert torch.equal(dx1, dx0), "dgrad differs (rep %d)" % rep
         assert rel_l2(s1.cpu(), s0.cpu()) < 1e-6          # partial-sum rows are grouped differently (fp32 order)
