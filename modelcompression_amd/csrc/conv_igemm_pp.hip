@@ -46,7 +46,34 @@ constexpr int WN = 64, WAVES_N = BN / WN;                     // 2 (M) x 4 (N) w
 constexpr int NT = 512;
 constexpr int CPR = BK / 8;                                   // 16-byte chunks per LDS row (64-byte rows)
 constexpr int B_SLOTS = BN * CPR, B_IT = B_SLOTS / NT;
-constexpr int TN = WN / 32;
+
+// MFMA shape of the wave tile: MS = 32 -> v_mfma_f32_32x32x16_f16 (two k16 steps per chunk, 16 accumulator
+// registers per block), MS = 16 -> v_mfma_f32_16x16x32_f16 (one k32 step, 4 registers per block; the same flops
+// per cycle on paper, a higher sustained clock in practice: MI355X_MICROARCH.md "DVFS give-back" (7)).
+template <int MS> struct Shape;
+template <> struct Shape<32> {
+    typedef f32x16_t acc_t;
+    static constexpr int AR = 16, KS = 2;
+    __device__ static __forceinline__ int swz4(int row) { return (row >> 2) & 3; }
+    __device__ static __forceinline__ int rowof(int r, int lane) { return mfma32_row(r, lane); }
+    __device__ static __forceinline__ acc_t mfma(h8_t a, h8_t b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Shape<16> {
+    typedef f32x4_t acc_t;
+    static constexpr int AR = 4, KS = 1;
+    // 64-byte rows read 16 rows x 4 chunks per instruction (lane = row + 16 * chunk): the ds_read_b128 lane groups
+    // {0-3,12-15,20-27}, ... hit 16 distinct 16-byte slots when chunk ^= {0,2,3,1}[(row >> 2) & 3]
+    __device__ static __forceinline__ int swz4(int row) {
+        const int q = (row >> 2) & 3;
+        return (((q & 1) ^ (q >> 1)) << 1) | (q >> 1);
+    }
+    __device__ static __forceinline__ int rowof(int r, int lane) { return (lane >> 4) * 4 + r; }
+    __device__ static __forceinline__ acc_t mfma(h8_t a, h8_t b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -58,9 +85,12 @@ __device__ __forceinline__ void wait_vm() {
 // BM = 256 (wave tile 128x64) or 192 (wave tile 96x64: 228 tiles instead of 172 for the 13x13 layers at B=64).
 // With BM = 192 the A tile is 1.5 DMA instructions per thread: waves 0-3 (= group 0) issue two A pieces, waves 4-7
 // one, so the counted waits differ per group.
-template <int EPI, int BM>
+template <int EPI, int BM, int MS>
 __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
-    constexpr int WM = BM / 2, TM = WM / 32;
+    typedef Shape<MS> SH;
+    typedef typename SH::acc_t acc_v;
+    constexpr int AR = SH::AR, KS = SH::KS;
+    constexpr int WM = BM / 2, TM = WM / MS, TN = WN / MS;
     constexpr int A_SLOTS = BM * CPR;
     constexpr int A_IT = (A_SLOTS + NT - 1) / NT;             // 2 (the second one only for waves 0-3 when BM = 192)
     constexpr bool RAGGED = A_SLOTS % NT != 0;
@@ -97,7 +127,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
     for (int it = 0; it < B_IT; ++it) {
         const int slot = it * NT + tid;
         const int row = slot / CPR, phys = slot % CPR;
-        bbase[it] = (long long)(nt * BN + row) * a.ktot + (phys ^ swz<CPR>(row)) * 8;
+        bbase[it] = (long long)(nt * BN + row) * a.ktot + (phys ^ SH::swz4(row)) * 8;
     }
 
     float s1[TN], s2[TN];
@@ -117,16 +147,16 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
             const int h = rem / a.W;
             const int w = rem - h * a.W;
             abase[it] = (long long)b * a.x_img_stride + (long long)h * a.x_row_stride + (long long)w * a.x_ld + a.x_off +
-                        (phys ^ swz<CPR>(row)) * 8;
+                        (phys ^ SH::swz4(row)) * 8;
         }
 
-        f32x16_t acc[TM][TN];
+        acc_v acc[TM][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < AR; ++r) acc[i][j][r] = 0.f;
 
         // Byte pointers of this thread's DMA pieces at chunk 0 (swizzle folded in); a chunk adds a wave-uniform
         // offset: activations tap_off[tap] + channel offset, weights q * BK.
@@ -159,10 +189,11 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
                 }
             }
         };
-        // Fragment addresses: row = tile row block + (lane & 31), so the swizzle term depends on the lane only and
-        // the k16 sub-step s flips bit 1 of the chunk index: two lane offsets per operand, constants for the rest.
-        const int lrow = lane & 31;
-        const int c0 = (lane >> 5) ^ swz<CPR>(lrow);
+        // Fragment addresses: row = tile row block + (lane & (MS-1)), so the swizzle term depends on the lane only.
+        // MS = 32: lane -> (row, k8 group lane >> 5), the k16 sub-step s flips bit 1 of the chunk index;
+        // MS = 16: lane -> (row, chunk lane >> 4), one read covers the whole 64-byte row.
+        const int lrow = lane & (MS - 1);
+        const int c0 = (lane / MS) ^ SH::swz4(lrow);
         const int a_off0 = ((wm * WM + lrow) * CPR + c0) * 16, a_off1 = ((wm * WM + lrow) * CPR + (c0 ^ 2)) * 16;
         const int b_off0 = A_SLOTS * 16 + ((wn * WN + lrow) * CPR + c0) * 16;
         const int b_off1 = A_SLOTS * 16 + ((wn * WN + lrow) * CPR + (c0 ^ 2)) * 16;
@@ -194,16 +225,16 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
             // chunk p+1 must have landed; chunk p+2 (issued in matrix phase p-1) may still be in flight
             wait_chunks(p + 2 < nchunks ? 1 : 0);
             const char* sbase = smem + (p & (NST - 1)) * STAGE_BYTES;
-            h8_t af[2][TM], bf[2][TN];
+            h8_t af[KS][TM], bf[KS][TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                bf[0][j] = *(const h8_t*)(sbase + b_off0 + j * (32 * CPR * 16));
-                bf[1][j] = *(const h8_t*)(sbase + b_off1 + j * (32 * CPR * 16));
+                bf[0][j] = *(const h8_t*)(sbase + b_off0 + j * (MS * CPR * 16));
+                if (KS == 2) bf[KS - 1][j] = *(const h8_t*)(sbase + b_off1 + j * (MS * CPR * 16));
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                af[0][i] = *(const h8_t*)(sbase + a_off0 + i * (32 * CPR * 16));
-                af[1][i] = *(const h8_t*)(sbase + a_off1 + i * (32 * CPR * 16));
+                af[0][i] = *(const h8_t*)(sbase + a_off0 + i * (MS * CPR * 16));
+                if (KS == 2) af[KS - 1][i] = *(const h8_t*)(sbase + a_off1 + i * (MS * CPR * 16));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired BEFORE the barrier (WAR rule above)
             __builtin_amdgcn_sched_barrier(0);
@@ -214,14 +245,14 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
             // time and the issue cost hides behind this wave's own MFMAs)
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < KS; ++s)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
-                        const int m = (s * TM + i) * TN + j;            // 0..15 (0..11 for BM = 192)
-                        constexpr int EVERY = 2 * TM * TN / 4;          // one DMA instruction per EVERY MFMAs
+                        acc[i][j] = SH::mfma(af[s][i], bf[s][j], acc[i][j]);
+                        const int m = (s * TM + i) * TN + j;            // 0 .. KS*TM*TN-1
+                        constexpr int EVERY = KS * TM * TN / 4;         // one DMA instruction per EVERY MFMAs
                         if (more && m % EVERY == 1) issue_piece(m / EVERY);
                     }
             __builtin_amdgcn_s_setprio(0);
@@ -247,14 +278,14 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mt * BM + wm * WM + i * 32 + mfma32_row(r, lane);
+                for (int r = 0; r < AR; ++r) {
+                    const int m = mt * BM + wm * WM + i * MS + SH::rowof(r, lane);
                     if (m < a.M) {
                         const int b = m / a.HW;
                         const int hw = m - b * a.HW;
 #pragma unroll
                         for (int j = 0; j < TN; ++j) {
-                            const int n = nt * BN + wn * WN + j * 32 + (lane & 31);
+                            const int n = nt * BN + wn * WN + j * MS + (lane & (MS - 1));
                             if (n < a.N) {
                                 float v = acc[i][j][r];
                                 if (a.bias) v += a.bias[n];
@@ -269,7 +300,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
             const int mlim = a.M - mt * BM;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int col = wn * WN + j * 32 + (lane & 31);
+                const int col = wn * WN + j * MS + (lane & (MS - 1));
                 float sc = 1.f, sh = 0.f;
                 if constexpr (EPI == MCAMD_EPI_PAD_F16) {
                     const int n = nt * BN + col;
@@ -281,8 +312,8 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = wm * WM + i * 32 + mfma32_row(r, lane);
+                    for (int r = 0; r < AR; ++r) {
+                        const int row = wm * WM + i * MS + SH::rowof(r, lane);
                         float v = acc[i][j][r];
                         if constexpr (EPI == MCAMD_EPI_PAD_F16) {
                             v = v * sc + sh;
@@ -323,17 +354,21 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
 
     if (EPI == MCAMD_EPI_RAW_F16 && a.stats) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+        for (int j = 0; j < TN; ++j) {   // lanes that hold the same column: l ^ 32 (and l ^ 16 for 16x16 blocks)
             s1[j] += __shfl_xor(s1[j], 32);
             s2[j] += __shfl_xor(s2[j], 32);
+            if (MS == 16) {
+                s1[j] += __shfl_xor(s1[j], 16);
+                s2[j] += __shfl_xor(s2[j], 16);
+            }
         }
         __syncthreads();
         float* red = (float*)smem;   // [BM/WM][2][BN]
-        if (lane < 32) {
+        if (lane < MS) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                red[(wm * 2 + 0) * BN + wn * WN + j * 32 + lane] = s1[j];
-                red[(wm * 2 + 1) * BN + wn * WN + j * 32 + lane] = s2[j];
+                red[(wm * 2 + 0) * BN + wn * WN + j * MS + lane] = s1[j];
+                red[(wm * 2 + 1) * BN + wn * WN + j * MS + lane] = s2[j];
             }
         }
         __syncthreads();
@@ -347,16 +382,17 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
     }
 }
 
-template <int EPI, int BM>
+template <int EPI, int BM, int MS>
 static void launch_pp(const IgemmArgs& a, int rows, int ntiles, hipStream_t st) {
     constexpr size_t ring = (size_t)NST * (BM * CPR + B_SLOTS) * 16;   // 128 KB / 112 KB: the ring, then the fp16 output tile
     static_assert((size_t)BM * BN * 2 <= ring, "output tile fits the ring");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_pp_kernel<EPI, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring);
+        (void)hipFuncSetAttribute((const void*)igemm_pp_kernel<EPI, BM, MS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)ring);
         attr_set = true;
     }
-    hipLaunchKernelGGL((igemm_pp_kernel<EPI, BM>), dim3(round_up_int(rows, 8) * ntiles + 8), dim3(NT), ring, st, a);
+    hipLaunchKernelGGL((igemm_pp_kernel<EPI, BM, MS>), dim3(round_up_int(rows, 8) * ntiles + 8), dim3(NT), ring, st, a);
 }
 
 // a.* filled as for mcamd_igemm_launch; needs N % 256 == 0 rows in the packed weights (they are padded to 256),
@@ -366,10 +402,13 @@ int mcamd_igemm_pp_launch(const IgemmArgs& a, int bm, int rows, int ntiles, hipS
         mcamd_set_error("igemm_pp: K per tap (%d) must be a multiple of %d, BM (%d) 256 or 192", a.cin_tap, BK, bm);
         return MCAMD_EINVAL;
     }
-#define PP_CASE(EPI_)                                                  \
-    do {                                                               \
-        if (bm == 256) launch_pp<EPI_, 256>(a, rows, ntiles, st);      \
-        else launch_pp<EPI_, 192>(a, rows, ntiles, st);                \
+    static const int ms = (getenv("MCAMD_PP_MFMA") && atoi(getenv("MCAMD_PP_MFMA")) == 32) ? 32 : 16;
+#define PP_CASE(EPI_)                                                      \
+    do {                                                                   \
+        if (bm == 256 && ms == 32) launch_pp<EPI_, 256, 32>(a, rows, ntiles, st);      \
+        else if (bm == 256) launch_pp<EPI_, 256, 16>(a, rows, ntiles, st); \
+        else if (ms == 32) launch_pp<EPI_, 192, 32>(a, rows, ntiles, st);  \
+        else launch_pp<EPI_, 192, 16>(a, rows, ntiles, st);                \
     } while (0)
     if (a.mode == MCAMD_EPI_NCHW_F32) PP_CASE(MCAMD_EPI_NCHW_F32);
     else if (a.mode == MCAMD_EPI_PAD_F16) PP_CASE(MCAMD_EPI_PAD_F16);
