@@ -45,7 +45,7 @@ for k in fetch:
     out[k] = e
 top = sorted(out.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches"])[:14]
 json.dump(dict(top), open("profiles/%s_pmc_per_kernel.json" % tag, "w"), indent=1)
-dom = [k for k in out if k.startswith("void igemm_kernel<")]
+dom = [k for k in out if k.startswith("void igemm_kernel<") or k.startswith("void igemm_pp_kernel<")]
 if dom:
     k = max(dom, key=lambda k: out[k]["launches"] * out[k]["avg_us"])
     json.dump({"kernel": k, "hbm_bytes_per_launch": out[k]["hbm_bytes_per_launch"], "launches_profiled": out[k]["launches"],
