@@ -1,6 +1,7 @@
 // Implicit-GEMM convolution for gfx950 (MI355X): forward and dgrad.
 //
-//   D[m][n] = sum_{tap, c} X[pixel(m) + tap][c] * Wp[n][tap*cin + c]
+//   D[m][n] = sum_{tap, c} X[pixel(m) + tap][c] * Wp[n][kpos(tap, c)]
+//   (kpos: the packed K axis runs [64-channel block][tap][channel], include/mcamd.h)
 //
 // m enumerates the B*H*W real output pixels, n the output channels.  X is a padded NHWC
 // fp16 activation (zero halo), so every tap address is in bounds and no im2col buffer or
