@@ -10,26 +10,57 @@
 // ------------------------------------------------------------------------------------
 // batch statistics -> affine coefficients
 // ------------------------------------------------------------------------------------
-// One block per 32 channels, 32 row groups x 32 channels: the slab rows are reduced in parallel
-// (coalesced 128-byte reads), then across the row groups through LDS, in double.
+// Slab reductions.  One block per 8 channels (the early layers have 32-64 channels and up to 2048 slab rows: a
+// block per 32 channels was one or two CUs reading 0.5 MB each, 25-29 us), 128 row groups x 8 channels per block:
+// rows are summed in double per thread, then over the 8 row groups of a wave by shuffles, then over the 16 waves
+// through LDS -- a fixed order, so the result does not depend on scheduling.
+constexpr int RED_CPB = 8, RED_RG = 128;
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, m);
+    hi = __shfl_xor(hi, m);
+    return __hiloint2double(hi, lo);
+}
+
+// returns (for threads of wave 0 .. any) the block total in threads with ry == 0: call from all 1024 threads
+__device__ __forceinline__ void block_reduce2(double& a, double& b, double (*red)[16][RED_CPB]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cx = threadIdx.x & (RED_CPB - 1);
+#pragma unroll
+    for (int m = RED_CPB; m < 64; m <<= 1) {   // lanes cx, cx+8, ..., cx+56 hold the same channel
+        a += shfl_xor_f64(a, m);
+        b += shfl_xor_f64(b, m);
+    }
+    if (lane < RED_CPB) {
+        red[0][wave][cx] = a;
+        red[1][wave][cx] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < RED_CPB) {
+        a = b = 0.0;
+        for (int w = 0; w < 16; ++w) {
+            a += red[0][w][cx];
+            b += red[1][w][cx];
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void bn_coeffs_kernel(const float* stats, int rows, int ld, int C, double count,
                                                          const float* gamma, const float* beta, float* rmean,
                                                          float* rvar, float momentum, float eps, int training,
                                                          float* scale, float* shift, float* save_mean,
                                                          float* save_invstd, const int* perm) {
-    __shared__ double red[2][32][33];
-    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cx;
+    __shared__ double red[2][16][RED_CPB];
+    const int cx = threadIdx.x & (RED_CPB - 1), ry = threadIdx.x / RED_CPB;
+    const int c = blockIdx.x * RED_CPB + cx;
     double s1 = 0.0, s2 = 0.0;
     if (training && c < C) {
-        for (int p = ry; p < rows; p += 32) {
+        for (int p = ry; p < rows; p += RED_RG) {
             s1 += (double)stats[((long long)p * 2 + 0) * ld + c];
             s2 += (double)stats[((long long)p * 2 + 1) * ld + c];
         }
     }
-    red[0][ry][cx] = s1;
-    red[1][ry][cx] = s2;
-    __syncthreads();
+    block_reduce2(s1, s2, red);
     if (ry != 0 || c >= C) return;
     // `perm` (optional): the statistics / coefficient vectors are in the kernels' PHYSICAL channel order
     // (kept filters first, engine.py filter compaction); the module's parameter vectors are in the
@@ -37,11 +68,6 @@ __global__ __launch_bounds__(1024) void bn_coeffs_kernel(const float* stats, int
     const int pc = perm ? perm[c] : c;
     double mean, var;
     if (training) {
-        s1 = s2 = 0.0;
-        for (int k = 0; k < 32; ++k) {
-            s1 += red[0][k][cx];
-            s2 += red[1][k][cx];
-        }
         mean = s1 / count;
         var = s2 / count - mean * mean;  // biased variance (normalisation)
         if (var < 0.0) var = 0.0;
@@ -336,25 +362,18 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(ActBwdArgs a) {
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* slab, int nblocks, int C, double count,
                                                                float inv_scale, float* dgamma, float* dbeta,
                                                                float* coef, const int* perm) {
-    __shared__ double red[2][32][33];
-    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cx;
+    __shared__ double red[2][16][RED_CPB];
+    const int cx = threadIdx.x & (RED_CPB - 1), ry = threadIdx.x / RED_CPB;
+    const int c = blockIdx.x * RED_CPB + cx;
     double sb = 0.0, sg = 0.0;
     if (c < C) {
-        for (int p = ry; p < nblocks; p += 32) {
+        for (int p = ry; p < nblocks; p += RED_RG) {
             sb += (double)slab[((long long)p * 2 + 0) * C + c];
             sg += (double)slab[((long long)p * 2 + 1) * C + c];
         }
     }
-    red[0][ry][cx] = sb;
-    red[1][ry][cx] = sg;
-    __syncthreads();
+    block_reduce2(sb, sg, red);
     if (ry != 0 || c >= C) return;
-    sb = sg = 0.0;
-    for (int k = 0; k < 32; ++k) {
-        sb += red[0][k][cx];
-        sg += red[1][k][cx];
-    }
     const int pc = perm ? perm[c] : c;   // parameter-order index of this physical channel
     if (dbeta) dbeta[pc] = (float)(sb * inv_scale);
     if (dgamma) dgamma[pc] = (float)(sg * inv_scale);
@@ -412,7 +431,7 @@ extern "C" int mcamd_bn_coeffs(const float* stats, int32_t stats_rows, int32_t s
                                float* save_mean, float* save_invstd, const int32_t* chan_perm, void* stream) {
     MCAMD_REQUIRE(C > 0 && gamma && beta && running_mean && running_var && scale && shift, "bn_coeffs: null argument");
     MCAMD_REQUIRE(!training || (stats && stats_rows > 0 && stats_ld >= C && count > 0), "bn_coeffs: bad statistics slab");
-    hipLaunchKernelGGL(bn_coeffs_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, stats, stats_rows,
+    hipLaunchKernelGGL(bn_coeffs_kernel, dim3((C + RED_CPB - 1) / RED_CPB), dim3(1024), 0, (hipStream_t)stream, stats, stats_rows,
                        stats_ld, C, (double)count, gamma, beta, running_mean, running_var, momentum, eps, training,
                        scale, shift, save_mean, save_invstd, (const int*)chan_perm);
     MCAMD_LAUNCH_CHECK("bn_coeffs");
@@ -519,7 +538,7 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
         MCAMD_REQUIRE(false, "bn_act_bwd: bad mode %d", d->mode);
     BWD_LAUNCH(0)
     MCAMD_LAUNCH_CHECK("bn_act_bwd reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + 31) / 32), dim3(1024), 0, st, (const float*)a.slab, grid, d->C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + RED_CPB - 1) / RED_CPB), dim3(1024), 0, st, (const float*)a.slab, grid, d->C,
                        count, 1.0f / d->grad_scale, d->dgamma, d->dbeta, coef, (const int*)d->chan_perm);
     MCAMD_LAUNCH_CHECK("bn_act_bwd finalize");
     BWD_LAUNCH(1)
