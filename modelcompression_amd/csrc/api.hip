@@ -384,7 +384,7 @@ extern "C" int mcamd_conv_dgrad(const mcamd_conv_geom* g, const void* dy, int32_
 // ---------------------------------------------------------------------------------------
 static WgradPlan wgrad_plan_for(const mcamd_conv_geom* g) {
     if (mcamd_wgrad_use9(g->ksize, g->stem, g->cout, cin_tap_of(g), g->W))
-        return mcamd_wgrad_plan9((long long)g->B * (g->H + 2) * (g->W + 2), g->cout, cin_tap_of(g));
+        return mcamd_wgrad_plan9((long long)g->B * (g->H + 2) * (g->W + 2), g->cout, cin_tap_of(g), g->W);
     return mcamd_wgrad_plan((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g), ntaps_of(g));
 }
 

@@ -282,8 +282,11 @@ __device__ __forceinline__ h8_t tr_frag_rows(const char* tile, int row0, int col
     return u.v;
 }
 
+// KP = pixels per step (32 or 64; steps_per_split / nsteps_total are in units of 32 pixels)
+template <int KP>
 __global__ __launch_bounds__(256, 2) void wgrad9_kernel(Wgrad9Args a) {
-    constexpr int KP = 32, RB = 128, CH = 8;   // 64 channels = 128 bytes = 8 chunks per row
+    constexpr int RB = 128, CH = 8;   // 64 channels = 128 bytes = 8 chunks per row
+    constexpr int U = KP / 32;        // 32-pixel units per step
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -299,12 +302,14 @@ __global__ __launch_bounds__(256, 2) void wgrad9_kernel(Wgrad9Args a) {
     const int split = item / ntiles;
     const int tile = item - split * ntiles;
     const int ot = tile / a.n_ctiles, ct = tile - ot * a.n_ctiles;
-    const int st0 = split * a.steps_per_split;
-    int st1 = st0 + a.steps_per_split;
-    if (st1 > a.nsteps_total) st1 = a.nsteps_total;
+    // steps of KP pixels; the split boundaries are in 32-pixel units (the host makes steps_per_split a multiple of U)
+    const int st0 = split * a.steps_per_split / U;
+    int st1 = (split + 1) * a.steps_per_split / U;
+    const int st_end = (a.nsteps_total + U - 1) / U;
+    if (st1 > st_end) st1 = st_end;
 
     // DMA sources: row r of the dY tile is padded pixel p0 + r; row r of the X window is p0 - S + r
-    const int arow = tid >> 3, achunk = (tid & 7) ^ tr_swz<RB>(arow);
+    const int arow = tid >> 3, achunk = (tid & 7) ^ tr_swz<RB>(arow);   // (+32 rows for the second dY piece: same swizzle)
     const half_t* dy_src = a.dy + a.dy_off + ot * 64 + achunk * 8 + (long long)arow * a.dy_ld;
     const half_t* x_base = a.x + a.x_off + ct * 64 - (long long)a.S * a.x_ld;
     const int x_iters = (R * CH + 255) >> 8;
@@ -319,10 +324,11 @@ __global__ __launch_bounds__(256, 2) void wgrad9_kernel(Wgrad9Args a) {
         const long long p0 = (long long)st * KP;
         char* sa = smem + buf * stage_bytes;
         char* sx = sa + a_bytes;
-        {
-            long long prow = p0 + arow;
-            const half_t* src = prow < a.P ? dy_src + p0 * a.dy_ld : a.dy + a.dy_off + ot * 64 + achunk * 8;  // pixel 0 = halo = 0
-            glds16(src, sa + wave * 1024);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            long long prow = p0 + 32 * u + arow;
+            const half_t* src = prow < a.P ? dy_src + (p0 + 32 * u) * a.dy_ld : a.dy + a.dy_off + ot * 64 + achunk * 8;  // pixel 0 = halo = 0
+            glds16(src, sa + u * 4096 + wave * 1024);
         }
         for (int it = 0; it < x_iters; ++it) {
             const int wslot = it * 256 + wave * 64;
@@ -552,13 +558,20 @@ static int pick_kp(int tmo, int tnc, int taps) {
 static int wgrad9_S(int W) { return round_up_int(W + 3, 4); }
 
 // plan of the padded-pixel 9-tap kernel (see wgrad9_kernel); P = padded pixels
-static WgradPlan wgrad9_plan(long long P, int cout, int cin_tap) {
+static WgradPlan wgrad9_plan(long long P, int cout, int cin_tap, int W) {
     WgradPlan p;
     memset(&p, 0, sizeof(p));
     p.nine = 1;
     p.tmo = p.tnc = 64;
     p.taps = 9;
+    // 64 pixels per step (half the barriers, 17-25 % fewer staged bytes per flop) while two double-buffered
+    // workgroups still fit the LDS; the big-image layers (window of 64 + 2(W+3) rows) stay at 32
     p.kp = 32;
+    {
+        const int want = env_int_w("MCAMD_WGRAD9_KP", 64);   // 128 (13x13 layers only) measured 1.8x SLOWER
+        for (int kp = 64; kp <= want && kp <= 128; kp *= 2)
+            if (2 * (size_t)(kp + kp + 2 * wgrad9_S(W)) * 128 <= 72 * 1024) p.kp = kp;   // two workgroups per CU: 2 x 72 KB
+    }
     p.rows_pad = round_up_int(cout, 64);
     p.n_otiles = p.rows_pad / 64;
     p.n_ctiles = cin_tap / 64;
@@ -580,6 +593,7 @@ static WgradPlan wgrad9_plan(long long P, int cout, int cin_tap) {
         }
     }
     long long sps = (nsteps + ns - 1) / ns;
+    sps = (sps + p.kp / 32 - 1) / (p.kp / 32) * (p.kp / 32);      // whole steps of kp pixels per split
     ns = (nsteps + sps - 1) / sps;
     p.nsplit = (int)ns;
     p.pix_per_split = (int)(sps * 32);
@@ -592,7 +606,7 @@ bool mcamd_wgrad_use9(int ksize, int stem, int cout, int cin_tap, int W) {
            W <= env_int_w("MCAMD_WGRAD9_MAXW", 208) && env_int_w("MCAMD_WGRAD9", 1);
 }
 
-WgradPlan mcamd_wgrad_plan9(long long P, int cout, int cin_tap) { return wgrad9_plan(P, cout, cin_tap); }
+WgradPlan mcamd_wgrad_plan9(long long P, int cout, int cin_tap, int W) { return wgrad9_plan(P, cout, cin_tap, W); }
 
 int mcamd_wgrad9_launch(const WgradArgs& w, const WgradPlan& p, int W, long long P, hipStream_t st) {
     Wgrad9Args a;
@@ -615,9 +629,22 @@ int mcamd_wgrad9_launch(const WgradArgs& w, const WgradPlan& p, int W, long long
     a.steps_per_split = p.pix_per_split / 32;
     a.nsteps_total = (int)((P + 31) / 32);
     const int R = 32 + 2 * a.S;
-    size_t lds = 2 * (size_t)(32 * 128 + R * 128);
     const int grid = round_up_int(p.n_otiles * p.n_ctiles * p.nsplit, 8);
-    hipLaunchKernelGGL(wgrad9_kernel, dim3(grid), dim3(256), lds, st, a);
+    if (p.kp == 128) {
+        const size_t lds = 2 * (size_t)(128 * 128 + (R + 96) * 128);
+        static bool attr_set = false;
+        if (lds > 64 * 1024 && !attr_set) {
+            (void)hipFuncSetAttribute((const void*)wgrad9_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(wgrad9_kernel<128>, dim3(grid), dim3(256), lds, st, a);
+    } else if (p.kp == 64) {
+        const size_t lds = 2 * (size_t)(64 * 128 + (R + 32) * 128);
+        hipLaunchKernelGGL(wgrad9_kernel<64>, dim3(grid), dim3(256), lds, st, a);
+    } else {
+        const size_t lds = 2 * (size_t)(32 * 128 + R * 128);
+        hipLaunchKernelGGL(wgrad9_kernel<32>, dim3(grid), dim3(256), lds, st, a);
+    }
     MCAMD_LAUNCH_CHECK("wgrad9");
     return MCAMD_OK;
 }

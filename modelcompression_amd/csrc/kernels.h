@@ -79,7 +79,7 @@ int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st);
 WgradPlan mcamd_wgrad_plan(long long M, int cout, int cin_tap, int ntaps);
 int mcamd_wgrad_launch(WgradArgs& a, const WgradPlan& p, hipStream_t st);
 bool mcamd_wgrad_use9(int ksize, int stem, int cout, int cin_tap, int W);
-WgradPlan mcamd_wgrad_plan9(long long P, int cout, int cin_tap);
+WgradPlan mcamd_wgrad_plan9(long long P, int cout, int cin_tap, int W);
 int mcamd_wgrad9_launch(const WgradArgs& w, const WgradPlan& p, int W, long long P, hipStream_t st);
 int mcamd_wgrad_finish_launch(const float* slab, const WgradPlan& p, int ktot, int cin_tap, int stem, int Cout, int Cin,
                               int ksize, const float* mask, float inv_scale, float* dw, const int* rmap, const int* cmap,
