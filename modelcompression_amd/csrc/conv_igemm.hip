@@ -31,8 +31,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 template <int BM, int BN, int WM, int WN, int BK, int NSTAGE, int EPI>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64,
-                              (WM * WN >= 128 * 128 ? 1 :   // 256 accumulator registers per lane: one wave per SIMD
-                               (BM / WM) * (BN / WN) >= 8 ? 2 : (BN >= 128 ? (NSTAGE * BK <= 96 ? 3 : 2) : (BN >= 64 ? 3 : 4))))
+                              (BN >= 128 ? (NSTAGE * BK <= 96 ? 3 : 2) : (BN >= 64 ? 3 : 4)))
 void igemm_kernel(IgemmArgs a) {
     constexpr int WAVES_N = BN / WN;
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
@@ -150,32 +149,11 @@ void igemm_kernel(IgemmArgs a) {
             else if (inflight == 1) wait_vmcnt<DMIN>();
             else wait_vmcnt<(NSTAGE > 3 ? 2 * DMIN : DMIN)>();
             __builtin_amdgcn_s_barrier();  // chunk q landed for every wave; every wave is done reading chunk q-1
-            // One wave per SIMD (128x128 wave tiles): nothing else hides the issue cost of the DMA instructions, so
-            // they are spread between the MFMAs of the first half of the chunk instead of issued in one block.
-            constexpr bool SPREAD = (TM * TN == 16);
-            const bool more = q + NSTAGE - 1 < nchunks;
-            int ns = sidx + NSTAGE - 1;
-            if (ns >= NSTAGE) ns -= NSTAGE;
-            if (!SPREAD && more) stage(q + NSTAGE - 1, ns);
-            auto stage_piece = [&](int piece) {     // piece in [0, A_IT + B_IT)
-                // issued unconditionally (straight-line loop body keeps the accumulators in place): past the last chunk
-                // the last chunk is fetched again into a ring slot nobody reads any more
-                const int qn = more ? q + NSTAGE - 1 : nchunks - 1;
-                const int sub = a.kb / BK > 0 ? a.kb / BK : 1, per_block = a.ntaps * sub;
-                const int cb = qn / per_block, r = qn - cb * per_block;
-                const int tap = r / sub;
-                const int koff = a.tap_off[tap] + cb * a.kb + (r - tap * sub) * BK;
-                char* sa2 = smem + ns * STAGE_BYTES;
-                char* sb2 = sa2 + A_SLOTS * 16;
-                if (piece < A_IT) {
-                    const int wslot = piece * NT + wave * 64;
-                    if (wslot < A_SLOTS) glds16(a.x + abase[piece] + koff, sa2 + wslot * 16);
-                } else {
-                    const int it = piece - A_IT;
-                    const int wslot = it * NT + wave * 64;
-                    if (wslot < B_SLOTS) glds16(a.w + bbase[it] + (long long)qn * BK, sb2 + wslot * 16);
-                }
-            };
+            if (q + NSTAGE - 1 < nchunks) {
+                int ns = sidx + NSTAGE - 1;
+                if (ns >= NSTAGE) ns -= NSTAGE;
+                stage(q + NSTAGE - 1, ns);
+            }
             const char* sa = smem + sidx * STAGE_BYTES;
             const char* sb = sa + A_SLOTS * 16;
             sidx = sidx + 1 == NSTAGE ? 0 : sidx + 1;
@@ -210,16 +188,8 @@ void igemm_kernel(IgemmArgs a) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
+                    for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s & M1][i], bf[s & M1][j], acc[i][j], 0, 0, 0);
-                        if (SPREAD) {
-                            // pieces per MFMA so that all of them are issued within the first half of the chunk
-                            constexpr int NP = A_IT + B_IT, SLOTS = (KS / 2 > 0 ? KS / 2 : 1) * TM * TN;
-                            constexpr int EVERY = SLOTS / NP > 0 ? SLOTS / NP : 1;
-                            const int m = s * TM * TN + i * TN + j;
-                            if (m % EVERY == EVERY - 1 && m / EVERY < NP) stage_piece(m / EVERY);
-                        }
-                    }
                 if (NSET == 2) __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -389,28 +359,6 @@ static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot) {
     t.bn = best;
     int want_bk = env_int("MCAMD_BK", 64);
     t.bk = (want_bk == 64 && cin_tap % 64 == 0) ? 64 : 32;
-    if ((t.bk == 64 || env_int("MCAMD_BIG_BK32", 0)) && best == 128 && env_int("MCAMD_BIG_TILES", 0)) {
-        if (env_int("MCAMD_BIG_BK32", 0) && cin_tap % 32 == 0) t.bk = 32;
-        // measured on MI355X (profiles/r01_*): TFLOP/s of a full machine ~ rinf * K / (K + k0); k0 is the
-        // epilogue + prologue cost of the tile shape expressed in K elements
-        struct Cand { int bm, bn; double rinf, k0; int per_cu; };
-        const Cand cands[3] = {{128, 128, 800.0, 250.0, 2}, {256, 128, 1000.0, 500.0, 1}, {256, 256, 1350.0, 2900.0, 1}};
-        double best_score = 0;
-        const int fbm = env_int("MCAMD_FORCE_BM", 0), fbn = env_int("MCAMD_FORCE_BN", 0);
-        for (int c = 0; c < 3; ++c) {
-            if (cands[c].bn == 256 && n % 256 != 0) continue;   // packed weights are padded to 256 rows only
-            long long tiles = ((M + cands[c].bm - 1) / cands[c].bm) * ((n + cands[c].bn - 1) / cands[c].bn);
-            long long slots = 256LL * cands[c].per_cu;
-            double fill = (double)tiles / (double)(((tiles + slots - 1) / slots) * slots);
-            double score = cands[c].rinf * ktot / (ktot + cands[c].k0) * fill;
-            if (fbm == cands[c].bm && (!fbn || fbn == cands[c].bn)) score += 1e9;   // forced (tests / sweeps)
-            if (score > best_score) {
-                best_score = score;
-                t.bm = cands[c].bm;
-                t.bn = cands[c].bn;
-            }
-        }
-    }
     // Tile quantisation: 2 workgroups per CU = 512 slots.  A 192-row tile (wave tile 96x64) often turns
     // a nearly empty last round into none (13x13 layers at B=64: 680 tiles -> 456); time ~ rounds x BM.
     if (t.bm == 128 && t.bn == 128 && t.bk == 64 && env_int("MCAMD_BM192", 1) &&
@@ -489,17 +437,6 @@ int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st) {
     }
     bool done = false;
     if (t.bm == 192 && t.bn == 128 && t.bk == 64) { launch_one<192, 128, 96, 64, 64, 2>(a, rows, ntiles, st); done = true; }
-    if (!done && t.bm == 256 && t.bn == 256 && t.bk == 32) { launch_one<256, 256, 128, 64, 32, 4>(a, rows, ntiles, st); done = true; }
-    if (!done && t.bm == 256 && t.bn == 128 && t.bk == 32) { launch_one<256, 128, 64, 64, 32, 4>(a, rows, ntiles, st); done = true; }
-    if (!done && t.bm == 256 && t.bn == 256 && env_int("MCAMD_BIG4", 0)) { launch_one<256, 256, 128, 128, 64, 2>(a, rows, ntiles, st); done = true; }
-    if (!done && t.bm == 256 && t.bn == 256) { launch_one<256, 256, 128, 64, 64, 2>(a, rows, ntiles, st); done = true; }
-    if (!done && t.bm == 256 && t.bn == 128) { launch_one<256, 128, 64, 64, 64, 2>(a, rows, ntiles, st); done = true; }
-    if (!done && t.bn == 128 && env_int("MCAMD_WAVES", 4) == 8) {   // 8-wave workgroups, one per CU
-        if (t.bk == 64 && stages == 3) { launch_one<128, 128, 32, 64, 64, 3>(a, rows, ntiles, st); done = true; }
-        else if (t.bk == 64 && stages == 2) { launch_one<128, 128, 32, 64, 64, 2>(a, rows, ntiles, st); done = true; }
-        else if (t.bk == 64 && stages == 4) { launch_one<128, 128, 32, 64, 64, 4>(a, rows, ntiles, st); done = true; }
-        else if (t.bk == 32 && stages == 4) { launch_one<128, 128, 32, 64, 32, 4>(a, rows, ntiles, st); done = true; }
-    }
     I_CASE(128, 64, 64, 32, 2) I_CASE(128, 64, 64, 32, 3) I_CASE(128, 64, 64, 32, 4)
     I_CASE(128, 64, 64, 64, 2) I_CASE(128, 64, 64, 64, 3)
     I_CASE(64, 64, 32, 32, 2) I_CASE(64, 64, 32, 32, 3) I_CASE(64, 64, 32, 32, 4)
