@@ -264,6 +264,7 @@ class Engine:
         self._mask_keys = None
         self._pack_key, self._pack_table, self._pack_keep = None, None, []
         self.compact = os.environ.get("MCAMD_COMPACT", "1") == "1"
+        self.fuse_eval = os.environ.get("MCAMD_FUSE_EVAL", "1") == "1"
         self.compact_gran = int(os.environ.get("MCAMD_COMPACT_GRAN", "0"))
         maxc = max(l.cout for l in self.layers)
         self.bwd_ws = torch.empty(ops.bn_act_bwd_workspace_bytes(maxc), dtype=torch.uint8, device=dev)
@@ -464,6 +465,16 @@ class Engine:
                     out += lay.border_map
                 continue
             bn = lay.bn
+            if (not training and self.fuse_eval and lay.mode == L.DST_PLAIN and lay.perm is None and lay.border is None
+                    and lay.out2_t is None):
+                # inference: BN (running statistics) + LeakyReLU in the conv epilogue, written straight into the
+                # consumer's padded buffer -- the raw output is never stored (one fp16 rounding per layer, no second pass)
+                ops.bn_coeffs(None, lay.cout, lay.M, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, False,
+                              lay.scale, lay.shift, lay.mean, lay.invstd, eps=bn.eps)
+                t = lay.out_t
+                self._timed('fwd', lay, ops.conv_fwd_padded, lay.geom_act, xin, lay.wp, self.bufs[t.buf], t.ld, t.choff,
+                            lay.scale, lay.shift, lay.slope)
+                continue
             self._timed('fwd', lay, ops.conv_fwd_raw, lay.geom_act, xin, lay.wp, lay.y, lay.cout, 0, lay.stats if training else None)
             ops.bn_coeffs(lay.stats if training else None, lay.cout, lay.M, bn.weight.data, bn.bias.data,
                           bn.running_mean, bn.running_var, training, lay.scale, lay.shift, lay.mean, lay.invstd,

@@ -260,6 +260,25 @@ def test_yolov2_eval_logits_vs_golden(dev, tmp_path):
     assert e < 5e-3
 
 
+def test_yolov2_eval_logits_b64_vs_oracle(dev):
+    """BASELINE batch size through every forward kernel as the bench runs it (ping-pong tiles included):
+    eval logits of all 64 images against the fp32 oracle on the CPU."""
+    blocks = O.parse_cfg(YOLOV2_VOC_CFG)
+    state = O.init_state(blocks, seed=2)
+    m = nets.Darknet(YOLOV2_VOC_CFG)
+    m.load_state_dict(state)
+    m.to(dev).eval()
+    x = torch.rand(64, 3, 416, 416, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        out = m(x.to(dev)).cpu()
+        ref = torch.cat([O.forward(blocks, state, x[i:i + 16], training=False) for i in range(0, 64, 16)])
+    e = rel_l2(out, ref)
+    worst = max(rel_l2(out[i], ref[i]) for i in range(64))
+    print("yolov2-voc eval logits at B=64: rel-L2 %.2e overall, %.2e worst image" % (e, worst))
+    assert out.shape == (64, 125, 13, 13)
+    assert e < 5e-3 and worst < 1e-2
+
+
 def test_yolov2_train_step_vs_oracle(dev):
     """Full-size fwd+bwd at B=2 against the fp32 oracle run here on the CPU.  Train-mode BN on a
     random-init 23-layer net amplifies any perturbation ~1.3x per layer, so the bound is the
