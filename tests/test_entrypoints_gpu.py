@@ -39,3 +39,19 @@ def test_predict_plumbing(dev, tmp_path):
 def test_smoke_entry(dev):
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_training_overfits_a_fixed_batch(dev):
+    """End-to-end training dynamics (tools/soak.py): RegionLoss + engine backward + SGD on one fixed synthetic batch
+    must drive the loss down by more than an order of magnitude -- a sign or scale error anywhere in the gradient
+    path shows up here even if it slipped through the per-kernel comparisons."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "80", "8", "none"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    last = [l for l in r.stdout.splitlines() if l.startswith("ok:")][-1]
+    first, final = (float(v) for v in last.split("loss")[1].replace("->", " ").split()[:2])
+    print(last)
+    assert final < 0.1 * first
