@@ -240,8 +240,8 @@ def main():
                      "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
                      "algorithmic_gflop_per_launch": round(dom_flop / max(dom_n, 1) / 1e9, 2),
                      "kernel": ("igemm9_kernel<0> 128x128x64 padded-pixel 9-tap (conv fwd + dgrad launches)" if dom_tile[3] == 9 else
-                                "igemm_pp_kernel<0,%d,16> %dx%dx%d ping-pong (conv fwd + dgrad launches of that instance)" % (
-                                    (dom_tile[0],) + dom_tile[:3]) if dom_tile[3] == 2 else
+                                "igemm_pp_kernel<0,%d,%d,16> %dx%dx%d ping-pong (conv fwd + dgrad launches of that instance)" % (
+                                    dom_tile[:2] + dom_tile[:3]) if dom_tile[3] == 2 else
                                 "igemm_kernel<%d,%d,..,%d,2,0> (conv fwd + dgrad launches of that instance)" % dom_tile[:3]),
                      "launches_per_step": dom_n // max(args.steps, 1),
                      "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4)},

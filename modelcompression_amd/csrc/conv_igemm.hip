@@ -326,25 +326,32 @@ static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot) {
         const int pp = env_int("MCAMD_PP", 1);
         if (pp && ktot >= 256 && n >= 128 && M >= 256) {
             bool use = pp == 2;
-            int bm = 256;
-            if (pp == 1 && n >= 256 && ktot >= 1024) {
+            int bm = 256, bn = 256;
+            if (pp == 1 && ktot >= env_int("MCAMD_PP_MINK", 1152)) {   // the short-K 1x1 layers gain < 10 % and are tiny
                 // Measured (profiles/): per busy CU the ping-pong tile is ~1.27x the 192x128 tile, but
                 // it runs ONE workgroup per CU, so it only pays when its tiles fill the 256 CUs well: 256 or 192 rows,
-                // whichever fills >= 80 % with the smaller rounds x rows.
-                long long best_cost = -1;
-                const int bms[2] = {256, 192};
-                for (int c = 0; c < 2; ++c) {
-                    const long long tiles = ((M + bms[c] - 1) / bms[c]) * ((n + 255) / 256);
-                    const long long rounds = (tiles + 255) / 256;
-                    if ((double)tiles / (double)(rounds * 256) < 0.8) continue;
-                    const long long cost = rounds * bms[c];
-                    if (best_cost < 0 || cost < best_cost) best_cost = cost, bm = bms[c];
+                // 256 or 128 columns (128 columns stage 1.3x the bytes per flop: costed at 0.8 of the 256-column rate),
+                // whichever fills >= 80 % with the smallest estimated time.
+                double best_cost = -1.0;
+                const int bms[2] = {256, 192}, bns[2] = {256, 128};
+                for (int cn = 0; cn < 2; ++cn) {
+                    if (n < bns[cn]) continue;
+                    for (int c = 0; c < 2; ++c) {
+                        const long long tiles = ((M + bms[c] - 1) / bms[c]) * ((n + bns[cn] - 1) / bns[cn]);
+                        const long long rounds = (tiles + 255) / 256;
+                        if ((double)tiles / (double)(rounds * 256) < 0.8) continue;
+                        const double cost = (double)rounds * bms[c] * bns[cn] / (bns[cn] == 256 ? 1.0 : 0.8);
+                        if (best_cost < 0 || cost < best_cost) best_cost = cost, bm = bms[c], bn = bns[cn];
+                    }
                 }
                 use = best_cost >= 0;
             }
-            if (pp >= 2 && env_int("MCAMD_PP_BM", 256) == 192) bm = 192;
+            if (pp >= 2) {
+                if (env_int("MCAMD_PP_BM", 256) == 192) bm = 192;
+                if (env_int("MCAMD_PP_BN", 256) == 128) bn = 128;
+            }
             if (use) {
-                t.bm = bm, t.bn = 256, t.bk = 32, t.kind = 2;
+                t.bm = bm, t.bn = bn, t.bk = 32, t.kind = 2;
                 return t;
             }
         }
@@ -428,7 +435,7 @@ int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st) {
     a.num_pslots = rows;
     a.num_ntiles = ntiles;
     a.xcd_order = env_int("MCAMD_XCD_ORDER", 1);
-    if (t.kind == 2) return mcamd_igemm_pp_launch(a, t.bm, rows, ntiles, st);
+    if (t.kind == 2) return mcamd_igemm_pp_launch(a, t.bm, t.bn, rows, ntiles, st);
     const int stages = env_int("MCAMD_STAGES", t.bk == 32 ? 3 : 2);
 #define I_CASE(BN_, WM_, WN_, BK_, ST_)                              \
     if (!done && t.bm == 128 && t.bn == BN_ && t.bk == BK_ && stages == ST_) { \

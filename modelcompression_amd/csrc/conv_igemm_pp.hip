@@ -41,11 +41,10 @@
 
 namespace {
 
-constexpr int BN = 256, BK = 32, NST = 4;
-constexpr int WN = 64, WAVES_N = BN / WN;                     // 2 (M) x 4 (N) waves
+constexpr int BK = 32, NST = 4;
+constexpr int WAVES_N = 4;                                    // 2 (M) x 4 (N) waves
 constexpr int NT = 512;
 constexpr int CPR = BK / 8;                                   // 16-byte chunks per LDS row (64-byte rows)
-constexpr int B_SLOTS = BN * CPR, B_IT = B_SLOTS / NT;
 
 // MFMA shape of the wave tile: MS = 32 -> v_mfma_f32_32x32x16_f16 (two k16 steps per chunk, 16 accumulator
 // registers per block), MS = 16 -> v_mfma_f32_16x16x32_f16 (one k32 step, 4 registers per block; the same flops
@@ -85,11 +84,15 @@ __device__ __forceinline__ void wait_vm() {
 // BM = 256 (wave tile 128x64) or 192 (wave tile 96x64: 228 tiles instead of 172 for the 13x13 layers at B=64).
 // With BM = 192 the A tile is 1.5 DMA instructions per thread: waves 0-3 (= group 0) issue two A pieces, waves 4-7
 // one, so the counted waits differ per group.
-template <int EPI, int BM, int MS>
+// BN = 256 or 128 columns (128: the layers with 128 output channels and the dgrads whose 256-column tiles
+// would be too few; staged bytes per flop are 1.3x those of 256 columns, still 0.75x those of 128x128).
+template <int EPI, int BM, int BN, int MS>
 __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
     typedef Shape<MS> SH;
     typedef typename SH::acc_t acc_v;
     constexpr int AR = SH::AR, KS = SH::KS;
+    constexpr int WN = BN / WAVES_N, B_SLOTS = BN * CPR, B_IT = B_SLOTS / NT;
+    static_assert(BN == 256 || BN == 128, "wave tiles of 64 or 32 columns");
     constexpr int WM = BM / 2, TM = WM / MS, TN = WN / MS;
     constexpr int A_SLOTS = BM * CPR;
     constexpr int A_IT = (A_SLOTS + NT - 1) / NT;             // 2 (the second one only for waves 0-3 when BM = 192)
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
             auto issue_piece = [&](int piece) {   // 0..3: A0, A1, B0, B1 of chunk p+3
                 if (piece < A_IT) {
                     if (piece * NT + wave * 64 < A_SLOTS) glds16(aptr[piece] + koff, sa + (piece * NT + wave * 64) * 16);
-                } else {
+                } else if (piece - A_IT < B_IT) {
                     glds16(bptr[piece - A_IT] + woff, sb + ((piece - A_IT) * NT + wave * 64) * 16);
                 }
             };
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
                     for (int j = 0; j < TN; ++j) {
                         acc[i][j] = SH::mfma(af[s][i], bf[s][j], acc[i][j]);
                         const int m = (s * TM + i) * TN + j;            // 0 .. KS*TM*TN-1
-                        constexpr int EVERY = KS * TM * TN / 4;         // one DMA instruction per EVERY MFMAs
+                        constexpr int EVERY = KS * TM * TN / 4;         // one DMA instruction per EVERY MFMAs (at most 4)
                         if (more && m % EVERY == 1) issue_piece(m / EVERY);
                     }
             __builtin_amdgcn_s_setprio(0);
@@ -382,38 +385,44 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
     }
 }
 
-template <int EPI, int BM, int MS>
+template <int EPI, int BM, int BN, int MS>
 static void launch_pp(const IgemmArgs& a, int rows, int ntiles, hipStream_t st) {
-    constexpr size_t ring = (size_t)NST * (BM * CPR + B_SLOTS) * 16;   // 128 KB / 112 KB: the ring, then the fp16 output tile
+    constexpr size_t ring = (size_t)NST * (BM + BN) * CPR * 16;   // <= 128 KB: the ring, then the fp16 output tile
     static_assert((size_t)BM * BN * 2 <= ring, "output tile fits the ring");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_pp_kernel<EPI, BM, MS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)igemm_pp_kernel<EPI, BM, BN, MS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)ring);
         attr_set = true;
     }
-    hipLaunchKernelGGL((igemm_pp_kernel<EPI, BM, MS>), dim3(round_up_int(rows, 8) * ntiles + 8), dim3(NT), ring, st, a);
+    hipLaunchKernelGGL((igemm_pp_kernel<EPI, BM, BN, MS>), dim3(round_up_int(rows, 8) * ntiles + 8), dim3(NT), ring, st, a);
 }
 
-// a.* filled as for mcamd_igemm_launch; needs N % 256 == 0 rows in the packed weights (they are padded to 256),
-// cin_tap % 32 == 0, at least one chunk.  bm = 256 or 192.
-int mcamd_igemm_pp_launch(const IgemmArgs& a, int bm, int rows, int ntiles, hipStream_t st) {
-    if (a.cin_tap % BK != 0 || a.ktot < BK || a.kb % BK != 0 || (bm != 256 && bm != 192)) {
-        mcamd_set_error("igemm_pp: K per tap (%d) must be a multiple of %d, BM (%d) 256 or 192", a.cin_tap, BK, bm);
+// a.* filled as for mcamd_igemm_launch; the packed weights are padded to 256 rows, cin_tap % 32 == 0, at least one
+// chunk.  bm = 256 or 192, bn = 256 or 128.
+int mcamd_igemm_pp_launch(const IgemmArgs& a, int bm, int bn, int rows, int ntiles, hipStream_t st) {
+    if (a.cin_tap % BK != 0 || a.ktot < BK || a.kb % BK != 0 || (bm != 256 && bm != 192) || (bn != 256 && bn != 128)) {
+        mcamd_set_error("igemm_pp: K per tap (%d) must be a multiple of %d, tile (%d x %d) 256|192 x 256|128", a.cin_tap, BK, bm, bn);
         return MCAMD_EINVAL;
     }
     static const int ms = (getenv("MCAMD_PP_MFMA") && atoi(getenv("MCAMD_PP_MFMA")) == 32) ? 32 : 16;
+#define PP_SHAPE(EPI_, BM_, BN_)                                           \
+    do {                                                                   \
+        if (ms == 32) launch_pp<EPI_, BM_, BN_, 32>(a, rows, ntiles, st);  \
+        else launch_pp<EPI_, BM_, BN_, 16>(a, rows, ntiles, st);           \
+    } while (0)
 #define PP_CASE(EPI_)                                                      \
     do {                                                                   \
-        if (bm == 256 && ms == 32) launch_pp<EPI_, 256, 32>(a, rows, ntiles, st);      \
-        else if (bm == 256) launch_pp<EPI_, 256, 16>(a, rows, ntiles, st); \
-        else if (ms == 32) launch_pp<EPI_, 192, 32>(a, rows, ntiles, st);  \
-        else launch_pp<EPI_, 192, 16>(a, rows, ntiles, st);                \
+        if (bm == 256 && bn == 256) PP_SHAPE(EPI_, 256, 256);              \
+        else if (bm == 192 && bn == 256) PP_SHAPE(EPI_, 192, 256);         \
+        else if (bm == 256) PP_SHAPE(EPI_, 256, 128);                      \
+        else PP_SHAPE(EPI_, 192, 128);                                     \
     } while (0)
     if (a.mode == MCAMD_EPI_NCHW_F32) PP_CASE(MCAMD_EPI_NCHW_F32);
     else if (a.mode == MCAMD_EPI_PAD_F16) PP_CASE(MCAMD_EPI_PAD_F16);
     else PP_CASE(MCAMD_EPI_RAW_F16);
 #undef PP_CASE
+#undef PP_SHAPE
     MCAMD_LAUNCH_CHECK("igemm_pp");
     return MCAMD_OK;
 }

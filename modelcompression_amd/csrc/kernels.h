@@ -72,7 +72,7 @@ struct WgradPlan {
 };
 
 void mcamd_igemm_tile(long long M, int n, int cin_tap, int ktot, int out[4]);   // {BM, BN, BK, kind}: kind 0 igemm_kernel, 2 igemm_pp_kernel
-int mcamd_igemm_pp_launch(const IgemmArgs& a, int bm, int rows, int ntiles, hipStream_t st);
+int mcamd_igemm_pp_launch(const IgemmArgs& a, int bm, int bn, int rows, int ntiles, hipStream_t st);
 int mcamd_igemm_rows(long long M, int n, int cin_tap, int ktot);
 int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st);
 

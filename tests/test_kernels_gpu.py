@@ -236,27 +236,29 @@ def test_pingpong_igemm_vs_igemm(dev, monkeypatch, B, H, W, cin, cout, k):
     assert t0[3] == 0
     monkeypatch.setenv("MCAMD_PP", "2")
     got = {}
-    for bm in (256, 192):
+    for bm, bn in ((256, 256), (192, 256), (256, 128), (192, 128)):
         monkeypatch.setenv("MCAMD_PP_BM", str(bm))
-        for rep in range(5):
+        monkeypatch.setenv("MCAMD_PP_BN", str(bn))
+        for rep in range(4):
             y1, s1, dx1, t1, t1d = run()
-            assert t1[3] == 2 and t1[:3] == (bm, 256, 32) and t1d[3] == (2 if cin >= 128 else 0)
+            assert t1[3] == 2 and t1[:3] == (bm, bn, 32) and t1d[3] == (2 if cin >= 128 else 0)
             if rep == 0:
-                got[bm] = (y1, s1, dx1)
-            assert torch.equal(y1, got[bm][0]) and torch.equal(dx1, got[bm][2]), "not reproducible (bm %d rep %d)" % (bm, rep)
+                got[(bm, bn)] = (y1, s1, dx1)
+            assert torch.equal(y1, got[(bm, bn)][0]) and torch.equal(dx1, got[(bm, bn)][2]), "not reproducible (%dx%d rep %d)" % (bm, bn, rep)
     mfma32 = os.environ.get("MCAMD_PP_MFMA", "16") == "32"      # read once by the library: set it for the whole process
-    for bm in (256, 192):
-        y1, s1, dx1 = got[bm]
+    for key in got:
+        y1, s1, dx1 = got[key]
         if mfma32:
             assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
         else:
             assert rel_l2(y1.float().cpu(), y0.float().cpu()) < 2e-4 and rel_l2(dx1.cpu(), dx0.cpu()) < 1e-5
         assert rel_l2(s1.cpu(), s0.cpu()) < 1e-4
-    assert torch.equal(got[256][0], got[192][0])
-    if cin >= 128:
-        assert torch.equal(got[256][2], got[192][2])
+    for key in got:
+        assert torch.equal(got[(256, 256)][0], got[key][0])
+        if cin >= 128:
+            assert torch.equal(got[(256, 256)][2], got[key][2])
     yr = F.conv2d(q16(x), q16(w), None, 1, (k - 1) // 2)
-    assert rel_l2(raw_to_nchw(got[192][0], B, H, W, cout, cout), yr) < TOL
+    assert rel_l2(raw_to_nchw(got[(192, 128)][0], B, H, W, cout, cout), yr) < TOL
 
 
 def test_pack_many_equals_per_layer_pack(dev):
