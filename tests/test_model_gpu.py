@@ -279,6 +279,27 @@ def test_yolov2_eval_logits_b64_vs_oracle(dev):
     assert e < 5e-3 and worst < 1e-2
 
 
+@pytest.mark.parametrize("B", [3, 37, 96])
+def test_yolov2_eval_is_batch_independent(dev, B):
+    """Size-independent property: in eval mode an image's logits do not depend on its batch (different batch sizes
+    pick different tile shapes and kernels -- 128x128, 192x128, ping-pong 192/256 x 256/128 -- but every output
+    element is accumulated over K in the same order, so the results agree to fp32 rounding of the MFMA shape)."""
+    blocks = O.parse_cfg(YOLOV2_VOC_CFG)
+    m = nets.Darknet(YOLOV2_VOC_CFG)
+    m.load_state_dict(O.init_state(blocks, seed=4))
+    m.to(dev).eval()
+    x = torch.rand(B, 3, 416, 416, generator=torch.Generator().manual_seed(B)).to(dev)
+    with torch.no_grad():
+        full = m(x)
+        m._engines = {}
+        alone = torch.cat([m(x[i:i + 1]) for i in (0, B // 2, B - 1)])
+    pick = full[[0, B // 2, B - 1]]
+    e = rel_l2(pick.cpu(), alone.cpu())
+    print("B=%d vs B=1: rel-L2 %.2e, torch.isfinite %s" % (B, e, bool(torch.isfinite(full).all())))
+    assert bool(torch.isfinite(full).all())
+    assert e < 1e-3      # only the MFMA shape (16x16x32 vs 32x32x16 summation inside one instruction) may differ
+
+
 def test_yolov2_train_step_vs_oracle(dev):
     """Full-size fwd+bwd at B=2 against the fp32 oracle run here on the CPU.  Train-mode BN on a
     random-init 23-layer net amplifies any perturbation ~1.3x per layer, so the bound is the
