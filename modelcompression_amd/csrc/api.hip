@@ -279,6 +279,7 @@ static int fill_epilogue(IgemmArgs& a, const mcamd_conv_epilogue* e, int n_out, 
 
 extern "C" int32_t mcamd_conv_stats_rows(const mcamd_conv_geom* g) {
     if (!g) return 0;
+    if (mcamd_stem_direct_ok(g->stem, g->cout, MCAMD_EPI_RAW_F16)) return mcamd_stem_rows((long long)g->B * g->H * g->W);
     if (mcamd_igemm9_ok(g->ksize, g->stem, g->cout, cin_tap_of(g), g->W, MCAMD_EPI_RAW_F16))
         return mcamd_igemm9_rows((long long)g->B * (g->H + 2) * (g->W + 2), g->cout);
     return mcamd_igemm_rows((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g), ntaps_of(g) * cin_tap_of(g));
@@ -288,6 +289,10 @@ extern "C" int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int
     if (check_geom(g, "conv_tile_info")) return MCAMD_EINVAL;
     MCAMD_REQUIRE(out, "conv_tile_info: null output");
     out[3] = 0;
+    if (!dgrad && mcamd_stem_direct_ok(g->stem, g->cout, MCAMD_EPI_RAW_F16)) {
+        out[0] = 32, out[1] = g->cout, out[2] = 48, out[3] = 1;   // stem_fwd_kernel (conv_stem.hip)
+        return MCAMD_OK;
+    }
     if (mcamd_igemm9_ok(g->ksize, g->stem, dgrad ? g->cin : g->cout, dgrad ? cout_p_of(g) : cin_tap_of(g), g->W,
                         MCAMD_EPI_RAW_F16)) {
         out[0] = 128, out[1] = 128, out[2] = 64, out[3] = 9;   // igemm9_kernel (padded-pixel 9-tap)
@@ -342,9 +347,18 @@ extern "C" int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const voi
     a.ktot = a.ntaps * a.cin_tap;
     fill_taps(g->ksize, g->stem, a.x_row_stride, g->x_ld, a.tap_off);
     const bool nine = epi && mcamd_igemm9_ok(g->ksize, g->stem, g->cout, a.cin_tap, g->W, epi->mode);
+    const bool stem_direct = epi && mcamd_stem_direct_ok(g->stem, g->cout, epi->mode);
     if (fill_epilogue(a, epi, g->cout, a.M, a.cin_tap, a.ktot, "conv_fwd",
-                      nine ? mcamd_igemm9_rows((long long)g->B * (g->H + 2) * (g->W + 2), g->cout) : -1))
+                      stem_direct ? mcamd_stem_rows(a.M)
+                                  : (nine ? mcamd_igemm9_rows((long long)g->B * (g->H + 2) * (g->W + 2), g->cout) : -1)))
         return MCAMD_EINVAL;
+    if (stem_direct) {       // conv_stem.hip: weights in registers, image fragments straight from global memory
+        StemArgs q;
+        q.x = a.x, q.w = a.w, q.y = (half_t*)a.y, q.stats = a.stats;
+        q.y_ld = a.y_ld, q.y_choff = a.y_choff, q.stats_ld = a.stats_ld;
+        q.H = g->H, q.W = g->W, q.HW = a.HW, q.M = a.M;
+        return mcamd_stem_launch(q, g->cout, (hipStream_t)stream);
+    }
     if (nine) return launch_igemm9(a, g, (hipStream_t)stream);
     return mcamd_igemm_launch(a, (hipStream_t)stream);
 }

@@ -30,6 +30,15 @@ struct IgemmArgs {
     int xcd_order;
 };
 
+struct StemArgs {        // conv_stem.hip: forward of the 3-channel first layer
+    const half_t* x;     // padded NHWC4 image
+    const half_t* w;     // packed stem weights [Npad][96]
+    half_t* y;           // raw output [M][y_ld]
+    float* stats;        // [grid][2][stats_ld] or NULL
+    int y_ld, y_choff, stats_ld;
+    int H, W, HW, M;
+};
+
 struct Igemm9Args {
     const half_t* x;      // padded pixel (0,0,0), channel 0 of the buffer (x_off added in the kernel)
     const half_t* w;      // packed weights [Npad][9*cin_tap]
@@ -86,6 +95,10 @@ int mcamd_wgrad_finish_launch(const float* slab, const WgradPlan& p, int ktot, i
                               hipStream_t st);
 int mcamd_colsum_launch(const half_t* dy, long long rows, int ld, int choff, int C, float inv_scale, float* out,
                         hipStream_t st);
+
+bool mcamd_stem_direct_ok(int stem, int cout, int mode);
+int mcamd_stem_rows(long long M);
+int mcamd_stem_launch(const StemArgs& a, int cout, hipStream_t st);
 
 bool mcamd_igemm9_ok(int ksize, int stem, int n, int cin_tap, int W, int mode);
 int mcamd_igemm9_S(int W);
