@@ -90,7 +90,8 @@ int32_t mcamd_conv_stats_rows(const mcamd_conv_geom* g);
 
 /* Workgroup tile {BM, BN, BK, kernel} the forward (dgrad == 0) or dgrad launch of this geometry uses:
  * kernel 0 = igemm_kernel<BM,BN,..,BK,..> (one tap per K chunk), 9 = igemm9_kernel (padded-pixel 9-tap),
- * 2 = igemm_pp_kernel (ping-pong, one workgroup per CU), 1 = stem_fwd_kernel (first layer, no LDS staging). */
+ * 2 = igemm_pp_kernel (ping-pong, one workgroup per CU), 1 = stem_fwd_kernel (first layer, no LDS staging),
+ * 4 = small3x3_kernel (narrow 3x3 layers on huge images, no LDS staging). */
 int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int32_t out[4]);
 
 /* Packed-weight sizes (elements of fp16) for a geometry. */

@@ -23,6 +23,7 @@ SOURCES = {
     "conv_igemm9.hip": [],
     "conv_igemm_pp.hip": [],
     "conv_stem.hip": [],
+    "conv_small.hip": [],
     "conv_wgrad.hip": [],
     "bn_act.hip": [],
     "prune.hip": ["-ffp-contract=off"],   # pinned fp32 arithmetic: no FMA contraction

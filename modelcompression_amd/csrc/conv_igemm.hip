@@ -306,7 +306,7 @@ void igemm_kernel(IgemmArgs a) {
 // ---------------------------------------------------------------------------------------
 struct TileCfg {
     int bm, bn, bk;
-    int kind;   // 0: igemm_kernel<...>, 2: igemm_pp_kernel (256x256 ping-pong, conv_igemm_pp.hip)
+    int kind;   // 0: igemm_kernel<...>, 2: igemm_pp_kernel (ping-pong, conv_igemm_pp.hip), 4: small3x3_kernel (conv_small.hip)
 };
 
 static int env_int(const char* name, int dflt) {
@@ -318,9 +318,13 @@ static int env_int(const char* name, int dflt) {
 // the kernel (bytes per flop = (1/BM + 1/BN) / 1), so bigger tiles are faster per tile, but the
 // machine has 256 CUs and the late layers have few tiles: pick the candidate with the best
 // (rate of the tile shape) x (fill of the last round of workgroups).
-static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot) {
+static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot, bool raw_epilogue = true) {
     TileCfg t;
     t.kind = 0;
+    if (raw_epilogue && mcamd_small3x3_ok(M, n, cin_tap, ktot)) {   // narrow 3x3 layers on huge images: no LDS staging at all
+        t.bm = 32, t.bn = round_up_int(n, 32), t.bk = cin_tap, t.kind = 4;
+        return t;
+    }
     // 256x256 ping-pong form (one workgroup per CU).  MCAMD_PP: 0 never, 1 by the cost rule below, 2 whenever legal.
     {
         const int pp = env_int("MCAMD_PP", 1);
@@ -392,6 +396,7 @@ int mcamd_igemm_rows(long long M, int n, int cin_tap, int ktot) {
     TileCfg t = pick_tile(M, n, cin_tap, ktot);
     int ntiles = (n + t.bn - 1) / t.bn;
     int mtiles = igemm_mtiles(M, t.bm);
+    if (t.kind == 4) return mcamd_small3x3_rows(M);
     int target = t.kind == 2 ? 256 : env_int("MCAMD_IGEMM_WGS", 2048);   // ping-pong: one workgroup per CU, persistent
     int p = target / ntiles;
     if (p < 1) p = 1;
@@ -424,7 +429,8 @@ static void launch_one(const IgemmArgs& a, int rows, int ntiles, hipStream_t st)
 
 // a.* geometry fields must be filled by the caller; picks the tile and launches.
 int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st) {
-    TileCfg t = pick_tile(a.M, a.N, a.cin_tap, a.ktot);
+    TileCfg t = pick_tile(a.M, a.N, a.cin_tap, a.ktot, a.mode == MCAMD_EPI_RAW_F16);   // stats slabs only exist with RAW
+    if (t.kind == 4) return mcamd_small3x3_launch(a, st);
     if (a.cin_tap % t.bk != 0 || a.ktot % t.bk != 0) {
         mcamd_set_error("igemm: K per tap (%d) must be a multiple of %d", a.cin_tap, t.bk);
         return MCAMD_EINVAL;

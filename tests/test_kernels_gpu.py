@@ -27,7 +27,22 @@ CONV_CASES = [
     (1, 26, 26, 64, 128, 1),
     (2, 13, 13, 256, 128, 3),
     (1, 12, 12, 40, 48, 3),       # channels padded to 64 (cin) / 48 outputs
+    (2, 48, 48, 32, 64, 3),       # M >= 4096 and narrow: small3x3_kernel<32, 2> forward, <64, 1> dgrad
+    (1, 70, 61, 24, 40, 3),       # small3x3_kernel<32, 2> / <64, 1>, ragged last 32-pixel group, padded channels
+    (2, 48, 50, 64, 32, 3),       # small3x3_kernel<64, 1> forward, <32, 2> dgrad
 ]
+
+
+def test_small3x3_kernel_is_selected(dev, monkeypatch):
+    monkeypatch.setenv("MCAMD_SMALL3X3", "2")                # also the 64-channel-input variants (off by default)
+    for (B, H, W, cin, cout, k) in CONV_CASES[-3:]:
+        g = ops.geom(B, H, W, k, cin, cout, ops.round_up(cin, 32))
+        assert ops.tile_info(g)[3] == 4 and ops.tile_info(g, dgrad=True)[3] == 4
+    g = ops.geom(2, 48, 48, 3, 64, 64, 64)                  # 72 weight fragments: generic kernel
+    assert ops.tile_info(g)[3] != 4
+    monkeypatch.setenv("MCAMD_SMALL3X3", "1")
+    g = ops.geom(2, 48, 48, 3, 32, 64, 32)
+    assert ops.tile_info(g)[3] == 4 and ops.tile_info(g, dgrad=True)[3] != 4
 
 
 def _rand_case(B, H, W, cin, cout, k, seed=0):
@@ -53,6 +68,7 @@ def test_layout_nchw_to_padded(dev, C, ld, choff):
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_raw_and_stats(dev, case, bk, monkeypatch):
     monkeypatch.setenv("MCAMD_BK", bk)
+    monkeypatch.setenv("MCAMD_SMALL3X3", "2" if bk == "64" else "1")
     B, H, W, cin, cout, k = case
     x, w = _rand_case(*case)
     xb, ld = to_padded(x.to(dev))
@@ -128,7 +144,8 @@ def test_conv_fwd_padded_epilogue(dev):
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_dgrad_wgrad(dev, case):
+def test_conv_dgrad_wgrad(dev, case, monkeypatch):
+    monkeypatch.setenv("MCAMD_SMALL3X3", "2")
     B, H, W, cin, cout, k = case
     x, w = _rand_case(*case, seed=11)
     gen = torch.Generator().manual_seed(12)
