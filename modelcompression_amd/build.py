@@ -25,6 +25,7 @@ SOURCES = {
     "conv_stem.hip": [],
     "conv_small.hip": [],
     "conv_wgrad.hip": [],
+    "conv_wgrad_stem.hip": [],
     "bn_act.hip": [],
     "prune.hip": ["-ffp-contract=off"],   # pinned fp32 arithmetic: no FMA contraction
 }

@@ -562,6 +562,7 @@ static WgradPlan wgrad9_plan(long long P, int cout, int cin_tap, int W) {
     WgradPlan p;
     memset(&p, 0, sizeof(p));
     p.nine = 1;
+    p.stemw = 0;
     p.tmo = p.tnc = 64;
     p.taps = 9;
     // 64 pixels per step (half the barriers, 17-25 % fewer staged bytes per flop) while two double-buffered
@@ -652,6 +653,7 @@ int mcamd_wgrad9_launch(const WgradArgs& w, const WgradPlan& p, int W, long long
 WgradPlan mcamd_wgrad_plan(long long M, int cout, int cin_tap, int ntaps) {
     WgradPlan p;
     p.nine = 0;
+    p.stemw = 0;
     p.tmo = pick_t(cout);
     p.tnc = pick_t(cin_tap);
     p.taps = pick_taps(p.tmo, p.tnc, ntaps);

@@ -307,8 +307,9 @@ def test_pack_many_equals_per_layer_pack(dev):
     assert torch.equal(only, want[0])
 
 
-def test_wgrad_stem(dev):
-    B, H, W, cout = 2, 24, 40, 32
+@pytest.mark.parametrize("B,H,W", [(2, 24, 40), (2, 40, 64), (3, 33, 96)])   # generic kernel | raw-window kernel (W % 32 == 0)
+def test_wgrad_stem(dev, B, H, W):
+    cout = 32
     gen = torch.Generator().manual_seed(13)
     x = torch.rand(B, 3, H, W, generator=gen)
     gy = torch.randn(B, cout, H, W, generator=gen)
