@@ -399,6 +399,8 @@ extern "C" int mcamd_conv_dgrad(const mcamd_conv_geom* g, const void* dy, int32_
 static WgradPlan wgrad_plan_for(const mcamd_conv_geom* g) {
     if (mcamd_wgrad_stem_ok(g->stem, g->cout, g->W, (long long)g->B * g->H * g->W))
         return mcamd_wgrad_stem_plan((long long)g->B * g->H * g->W);
+    if (mcamd_wgrad_win_ok(g->ksize, g->stem, g->cout, cin_tap_of(g), g->W, (long long)g->B * g->H * g->W))
+        return mcamd_wgrad_win_plan((long long)g->B * g->H * g->W, g->cout);
     if (mcamd_wgrad_use9(g->ksize, g->stem, g->cout, cin_tap_of(g), g->W))
         return mcamd_wgrad_plan9((long long)g->B * (g->H + 2) * (g->W + 2), g->cout, cin_tap_of(g), g->W);
     return mcamd_wgrad_plan((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g), ntaps_of(g));
@@ -449,7 +451,8 @@ extern "C" int mcamd_conv_wgrad(const mcamd_conv_geom* g, const void* x, const v
     a.ktot = ntaps * cin_tap;
     fill_taps(g->ksize, g->stem, a.x_row_stride, g->x_ld, a.tap_off);
     int rc = p.nine    ? mcamd_wgrad9_launch(a, p, g->W, (long long)g->B * (g->H + 2) * (g->W + 2), st)
-             : p.stemw ? mcamd_wgrad_stem_launch(a, p, st)
+             : p.stemw == 1 ? mcamd_wgrad_stem_launch(a, p, st)
+             : p.stemw == 2 ? mcamd_wgrad_win_launch(a, p, st)
                        : mcamd_wgrad_launch(a, p, st);
     if (rc) return rc;
     rc = mcamd_wgrad_finish_launch((const float*)workspace, p, a.ktot, cin_tap, g->stem, g->cout, g->cin, g->ksize,

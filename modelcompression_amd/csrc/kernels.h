@@ -77,7 +77,7 @@ struct WgradArgs {
 struct WgradPlan {
     int tmo, tnc, taps, kp, rows_pad, n_otiles, n_ctiles, n_tapgroups, nsplit, pix_per_split;
     int nine;   // 1: padded-pixel 9-tap kernel (wgrad9_kernel)
-    int stemw;  // 1: raw-window first-layer kernel (wgrad_stem_kernel)
+    int stemw;  // 1: raw-window first-layer kernel (wgrad_stem_kernel), 2: raw-window 32-channel kernel (wgrad_win_kernel)
     size_t bytes;
 };
 
@@ -91,6 +91,9 @@ int mcamd_wgrad_launch(WgradArgs& a, const WgradPlan& p, hipStream_t st);
 bool mcamd_wgrad_stem_ok(int stem, int cout, int W, long long M);   // conv_wgrad_stem.hip
 WgradPlan mcamd_wgrad_stem_plan(long long M);
 int mcamd_wgrad_stem_launch(WgradArgs& a, const WgradPlan& p, hipStream_t st);
+bool mcamd_wgrad_win_ok(int ksize, int stem, int cout, int cin_tap, int W, long long M);
+WgradPlan mcamd_wgrad_win_plan(long long M, int cout);
+int mcamd_wgrad_win_launch(WgradArgs& a, const WgradPlan& p, hipStream_t st);
 bool mcamd_wgrad_use9(int ksize, int stem, int cout, int cin_tap, int W);
 WgradPlan mcamd_wgrad_plan9(long long P, int cout, int cin_tap, int W);
 int mcamd_wgrad9_launch(const WgradArgs& w, const WgradPlan& p, int W, long long P, hipStream_t st);

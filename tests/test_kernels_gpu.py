@@ -30,12 +30,14 @@ CONV_CASES = [
     (2, 48, 48, 32, 64, 3),       # M >= 4096 and narrow: small3x3_kernel<32, 2> forward, <64, 1> dgrad
     (1, 70, 61, 24, 40, 3),       # small3x3_kernel<32, 2> / <64, 1>, ragged last 32-pixel group, padded channels
     (2, 48, 50, 64, 32, 3),       # small3x3_kernel<64, 1> forward, <32, 2> dgrad
+    (3, 40, 48, 32, 64, 3),       # wgrad_win_kernel<2> (W % 16 == 0, 32 input channels)
+    (2, 50, 64, 24, 32, 3),       # wgrad_win_kernel<1>, padded input channels
 ]
 
 
 def test_small3x3_kernel_is_selected(dev, monkeypatch):
     monkeypatch.setenv("MCAMD_SMALL3X3", "2")                # also the 64-channel-input variants (off by default)
-    for (B, H, W, cin, cout, k) in CONV_CASES[-3:]:
+    for (B, H, W, cin, cout, k) in CONV_CASES[-5:-2]:
         g = ops.geom(B, H, W, k, cin, cout, ops.round_up(cin, 32))
         assert ops.tile_info(g)[3] == 4 and ops.tile_info(g, dgrad=True)[3] == 4
     g = ops.geom(2, 48, 48, 3, 64, 64, 64)                  # 72 weight fragments: generic kernel
