@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     // provably wave-uniform (readfirstlane): otherwise hipcc wraps every LDS-DMA in a waterfall loop
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave % NI, part = wave / NI;
+    const unsigned smem_addr = lds_addr_of(smem);
 
     // XCD-aware order: work items are numbered split-major (all tiles of a split stream the same
     // dY / X pixel range); blocks are dealt round-robin to the 8 XCDs, so XCD x takes the
@@ -156,26 +157,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (st + 1 < nsteps) stage((st + 1) & 1);
-        const char* sa = smem + (st & 1) * STAGE_BYTES;
-        const char* sb = sa + A_SLOTS * 16;
+        const unsigned sa = smem_addr + (st & 1) * STAGE_BYTES;
+        const unsigned sb = sa + A_SLOTS * 16;
 #pragma unroll
         for (int s = 0; s < KP / 16; ++s) {
             if constexpr (SQ) {
                 // 128x128, one tap: 2x2 waves of 64x64 (2 A + 2 B fragments feed 4 MFMAs)
-                h8_t af2[2], bf2[2];
+                Frag af2[2], bf2[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) af2[i] = tr_frag<RBA>(sa, s, (wave >> 1) * 64 + i * 32, lane);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) bf2[j] = tr_frag<RBB>(sb, s, (wave & 1) * 64 + j * 32, lane);
+                lds_wait_all(af2[0]);
+                tie(af2[1]), tie(bf2[0]), tie(bf2[1]);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af2[i], bf2[j], acc[i * 2 + j], 0, 0, 0);
+                        acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af2[i].v(), bf2[j].v(), acc[i * 2 + j], 0, 0, 0);
             } else {
                 // all fragments of this k16 step first, then the MFMAs back to back
-                const h8_t af = tr_frag<RBA>(sa, s, wi * 32, lane);
-                h8_t bf[NACC];
+                Frag af = tr_frag<RBA>(sa, s, wi * 32, lane);
+                Frag bf[NACC];
 #pragma unroll
                 for (int idx = 0; idx < NACC; ++idx) {
                     int q = part + WPI * idx;     // (tap, cin-block) task of this wave
@@ -183,9 +186,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
                     const int tapl = q / NJ, jn = q - tapl * NJ;
                     bf[idx] = tr_frag<RBB>(sb + tapl * (KP * RBB), s, jn * 32, lane);
                 }
+                lds_wait_all(af);
 #pragma unroll
-                for (int idx = 0; idx < NACC; ++idx)
-                    acc[idx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[idx], acc[idx], 0, 0, 0);
+                for (int idx = 0; idx < NACC; ++idx) {
+                    tie(bf[idx]);
+                    acc[idx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af.v(), bf[idx].v(), acc[idx], 0, 0, 0);
+                }
             }
         }
     }
@@ -232,25 +238,6 @@ struct Wgrad9Args {
     int rows_pad, ktot, cin_tap;
     int n_ctiles, n_otiles, nsplit, steps_per_split, nsteps_total;
 };
-
-template <int RB>
-__device__ __forceinline__ h8_t tr_frag_rows(const char* tile, int row0, int colbase, int lane) {
-    // as tr_frag, but the 16 k-rows start at an arbitrary LDS row `row0` (+8 for the upper half-wave)
-    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
-    const int row = row0 + 8 * (g >> 1) + q;
-    const int cb = colbase + 16 * (g & 1);
-    const int off = (cb + 4 * p) * 2;
-    const char* p0 = tile + row * RB + ((((off >> 4) ^ tr_swz<RB>(row)) << 4) | (off & 15));
-    const int row4 = row + 4;
-    const char* p1 = tile + row4 * RB + ((((off >> 4) ^ tr_swz<RB>(row4)) << 4) | (off & 15));
-    union {
-        fp16x4_t h[2];
-        h8_t v;
-    } u;
-    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)p0);
-    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)p1);
-    return u.v;
-}
 
 // KP = pixels per step (32 or 64; steps_per_split / nsteps_total are in units of 32 pixels)
 template <int KP>
@@ -319,12 +306,12 @@ __global__ __launch_bounds__(256, 2) void wgrad9_kernel(Wgrad9Args a) {
         const char* sx = sa + a_bytes;
 #pragma unroll
         for (int s = 0; s < KP / 16; ++s) {
-            const h8_t af = tr_frag_rows<RB>(sa, 16 * s, wi * 32, lane);
+            const h8_t af = tr_frag_rows_builtin<RB>(sa, 16 * s, wi * 32, lane);
             h8_t bf[9];
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int shift = (t / 3 - 1) * a.W2 + (t % 3 - 1);
-                bf[t] = tr_frag_rows<RB>(sx, 16 * s + a.S + shift, wj * 32, lane);
+                bf[t] = tr_frag_rows_builtin<RB>(sx, 16 * s + a.S + shift, wj * 32, lane);
             }
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[t], acc[t], 0, 0, 0);

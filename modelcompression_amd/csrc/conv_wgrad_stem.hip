@@ -23,33 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-// The transposing reads are issued as inline assembly on purpose: hipcc's waitcnt pass makes every LDS read it can
-// see wait for ALL outstanding LDS-DMA (`s_waitcnt vmcnt(0)` in front of the first ds_read of a step -- the
-// builtin form of these kernels drained the whole ring every step, 230 us for wgrad_win_kernel), and it cannot be
-// told that the ring stages are disjoint.  The price: lgkmcnt is ours to count too (lds_wait*() below, tied to the
-// fragment registers so that no MFMA can be scheduled above its wait).
-typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-
-template <int OFF>
-__device__ __forceinline__ u32x2_t tr_read4(unsigned lds_addr) {
-    u32x2_t v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF) : "memory");
-    return v;
-}
-__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
-    return (unsigned)(uintptr_t)((__attribute__((address_space(3))) const char*)p);
-}
-struct Frag {
-    u32x2_t lo, hi;
-    __device__ __forceinline__ h8_t v() const {
-        union { u32x2_t u[2]; h8_t h; } c;
-        c.u[0] = lo, c.u[1] = hi;
-        return c.h;
-    }
-};
-__device__ __forceinline__ void lds_wait_all(Frag& f) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.lo), "+v"(f.hi)::"memory"); }
-__device__ __forceinline__ void tie(Frag& f) { asm volatile("" : "+v"(f.lo), "+v"(f.hi)); }
-
+// (transposing reads: inline assembly, see tr_frag.h)
 template <int NS>
 __global__ __launch_bounds__(256) void wgrad_stem_kernel(WgradArgs a) {
     constexpr int DY_BYTES = 2048, X_ROW = 272, STAGE = 3072;
