@@ -329,6 +329,213 @@ __global__ __launch_bounds__(256, 2) void wgrad9_kernel(Wgrad9Args a) {
         }
 }
 
+// ---------------------------------------------------------------------------------------
+// Wide form of the 9-tap kernel: workgroup = 8 waves = 128 filters x 64 input channels x 9 taps.
+//
+// wgrad9_kernel is bound by the LDS read rate, not by the MFMAs: a wave owns one 32x32 block for all nine taps, so
+// every B fragment it reads feeds ONE MFMA (20 fragments per 9 MFMAs; 8 waves x 40 ds_read_b64_tr_b16 x 2
+// cycles = 640 LDS cycles against 576 MFMA cycles per SIMD), and its two 64x64 workgroups per CU stage 42 KB per
+// 64 pixels.  Here wave (wi, wj, wh) owns filters [64 wi, 64 wi + 64) x channels [32 wj, 32 wj + 32) x taps
+// {0..4} (wh = 0) or {5..8} (wh = 1): every B fragment feeds two MFMAs, 7 (6) fragments per 10 (8) MFMAs -> 208 LDS
+// cycles per 576 MFMA cycles; waves w and w + 4 share a SIMD, so each SIMD carries one 5-tap and one 4-tap wave.
+// One workgroup per CU stages 16 KB of dY + one X window per 64 pixels (29 KB at 13x13: -30 %), in an NS-stage ring
+// with counted vmcnt (the transposing reads are inline assembly, see tr_frag.h: with the builtin the compiler
+// drains the ring before the first read of a step and a lone workgroup would never overlap DMA with MFMA).
+// Fragments are double-buffered across the k16 sub-steps: the reads of sub-step s + 1 are issued before the MFMAs
+// of sub-step s.
+__device__ __forceinline__ void wait_vm_dyn(int n) {
+    // n is wave-uniform (scalar branches); s_waitcnt takes an immediate
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // more than asked for is always safe
+    }
+}
+
+// lane offset (bytes from the tile start) of the first of a fragment's two transposing reads; the second one is 4
+// rows further (same swizzle for 128- and 256-byte rows), sub-step s is 16 rows further (same swizzle again), so both
+// are `offset:` immediates of the read instruction and a fragment costs one address register for the whole kernel
+template <int RB>
+__device__ __forceinline__ unsigned tr_lane_off(int row0, int colbase, int lane) {
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+    const int row = row0 + 8 * (g >> 1) + q;
+    const int off = (colbase + 16 * (g & 1) + 4 * p) * 2;
+    return row * RB + ((((off >> 4) ^ tr_swz<RB>(row)) << 4) | (off & 15));
+}
+
+template <int S_, int NT>
+__device__ __forceinline__ void w9w_issue(unsigned sa, unsigned sx, const unsigned (&a_lo)[2], const unsigned (&b_lo)[5],
+                                          Frag (&af)[2], Frag (&bf)[NT]) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        af[ni].lo = tr_read4<S_ * 16 * 256>(sa + a_lo[ni]);
+        af[ni].hi = tr_read4<S_ * 16 * 256 + 4 * 256>(sa + a_lo[ni]);
+    }
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) {
+        bf[tl].lo = tr_read4<S_ * 16 * 128>(sx + b_lo[tl]);
+        bf[tl].hi = tr_read4<S_ * 16 * 128 + 4 * 128>(sx + b_lo[tl]);
+    }
+}
+
+// `five`: wave-uniform; the 4-tap waves skip the fifth pair of MFMAs (a small scalar branch: one code path for
+// both kinds of wave -- two instantiations of the whole stage made hipcc spill 270 registers around the 160
+// accumulator registers they share)
+template <int NT>
+__device__ __forceinline__ void w9w_mfma(Frag (&af)[2], Frag (&bf)[NT], f32x16_t (&acc)[2][5], bool five) {
+    tie(af[0]), tie(af[1]);
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) {
+        tie(bf[tl]);
+        if (tl < 4 || five) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                acc[ni][tl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ni].v(), bf[tl].v(), acc[ni][tl], 0, 0, 0);
+        }
+    }
+}
+
+// one stage of KP = 64 pixels: four k16 sub-steps, fragments double-buffered (reads of s + 1 before the MFMAs of s)
+__device__ __forceinline__ void w9w_stage_mfma(unsigned sa, unsigned sx, const unsigned (&a_lo)[2], const unsigned (&b_lo)[5],
+                                               f32x16_t (&acc)[2][5], bool five) {
+    constexpr int NT = 5;
+    Frag af0[2], bf0[NT], af1[2], bf1[NT];
+    w9w_issue<0, NT>(sa, sx, a_lo, b_lo, af0, bf0);
+    lds_wait_all(af0[0]);
+    w9w_issue<1, NT>(sa, sx, a_lo, b_lo, af1, bf1);
+    w9w_mfma<NT>(af0, bf0, acc, five);
+    lds_wait_all(af1[0]);
+    w9w_issue<2, NT>(sa, sx, a_lo, b_lo, af0, bf0);
+    w9w_mfma<NT>(af1, bf1, acc, five);
+    lds_wait_all(af0[0]);
+    w9w_issue<3, NT>(sa, sx, a_lo, b_lo, af1, bf1);
+    w9w_mfma<NT>(af0, bf0, acc, five);
+    lds_wait_all(af1[0]);
+    w9w_mfma<NT>(af1, bf1, acc, five);
+}
+
+template <int KP, int NS>
+__global__ __launch_bounds__(512, 1) void wgrad9w_kernel(Wgrad9Args a) {
+    constexpr int U = KP / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave & 1, wj = (wave >> 1) & 1, wh = wave >> 2;
+    const unsigned smem_addr = lds_addr_of(smem);
+    const int R = KP + 2 * a.S;                 // window rows (multiple of 8)
+    const int a_bytes = KP * 256, x_bytes = R * 128, stage_bytes = a_bytes + x_bytes;
+
+    const int ntiles = a.n_otiles * a.n_ctiles;
+    const int total_items = ntiles * a.nsplit;
+    const int chunk = (total_items + 7) >> 3;
+    const int item = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || item >= total_items) return;
+    const int split = item / ntiles;
+    const int tile = item - split * ntiles;
+    const int ot = tile / a.n_ctiles, ct = tile - ot * a.n_ctiles;
+    const int st0 = split * a.steps_per_split / U;
+    int st1 = (split + 1) * a.steps_per_split / U;
+    const int st_end = (a.nsteps_total + U - 1) / U;
+    if (st1 > st_end) st1 = st_end;
+
+    // DMA roles: dY tile row r = padded pixel p0 + r (16 chunks of 8 filters), X window row r = pixel p0 - S + r
+    constexpr int A_IT = KP * 16 / 512;
+    const half_t* dy_base = a.dy + a.dy_off + ot * 128;
+    const half_t* x_base = a.x + a.x_off + ct * 64 - (long long)a.S * a.x_ld;
+    const int x_iters = (R * 8 + 511) >> 9;
+    int cnt = A_IT;                              // DMA instructions this wave issues per stage
+    for (int it = 0; it < x_iters; ++it) cnt += (it * 512 + wave * 64 < R * 8) ? 1 : 0;
+
+    auto stage = [&](int st, int buf) {
+        const long long p0 = (long long)st * KP;
+        char* sa = smem + buf * stage_bytes;
+        char* sx = sa + a_bytes;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int piece = it * 512 + tid;
+            const int row = piece >> 4, ch = (piece & 15) ^ tr_swz<256>(row);
+            const long long prow = p0 + row;
+            const half_t* src = dy_base + ch * 8 + (prow < a.P ? prow * a.dy_ld : 0);   // pixel 0 = halo = 0
+            glds16(src, sa + (it * 512 + wave * 64) * 16);
+        }
+        for (int it = 0; it < x_iters; ++it) {
+            const int wslot = it * 512 + wave * 64;
+            if (wslot < R * 8) {
+                const int slot = wslot + lane;
+                const int row = slot >> 3, chx = (slot & 7) ^ tr_swz<128>(row);
+                glds16(x_base + (p0 + row) * a.x_ld + chx * 8, sx + wslot * 16);
+            }
+        }
+    };
+
+    f32x16_t acc[2][5];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ni][t][r] = 0.f;
+
+    static_assert(KP == 64, "w9w_stage_mfma is written out for four k16 sub-steps");
+    unsigned a_lo[2], b_lo[5];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) a_lo[ni] = tr_lane_off<256>(0, wi * 64 + ni * 32, lane);
+#pragma unroll
+    for (int tl = 0; tl < 5; ++tl) {
+        int t = (wh ? 5 : 0) + tl;
+        if (t > 8) t = 8;                          // the 4-tap waves never read their fifth slot
+        const int shift = (t / 3 - 1) * a.W2 + (t % 3 - 1);
+        b_lo[tl] = tr_lane_off<128>(a.S + shift, wj * 32, lane);
+    }
+
+#pragma unroll
+    for (int k = 0; k < NS - 1; ++k)
+        if (st0 + k < st1) stage(st0 + k, k);
+    int slot = 0;
+    for (int st = st0; st < st1; ++st) {
+        int ahead = st1 - 1 - st;                 // younger stages already in flight
+        if (ahead > NS - 2) ahead = NS - 2;
+        wait_vm_dyn(ahead * cnt);
+        __syncthreads();                          // everybody's pieces of stage st landed; everybody left stage st - 1
+        if (st + NS - 1 < st1) {
+            int nslot = slot + NS - 1;
+            if (nslot >= NS) nslot -= NS;
+            stage(st + NS - 1, nslot);
+        }
+        const unsigned sa = smem_addr + slot * stage_bytes;
+        const unsigned sx = sa + a_bytes;
+        w9w_stage_mfma(sa, sx, a_lo, b_lo, acc, wh == 0);
+        slot = slot + 1 == NS ? 0 : slot + 1;
+    }
+
+    float* out = a.slab + (long long)split * a.rows_pad * a.ktot;
+    const int t0 = wh ? 5 : 0, nt = wh ? 4 : 5;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int tl = 0; tl < 5; ++tl) {
+            if (tl < nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = ot * 128 + wi * 64 + ni * 32 + mfma32_row(r, lane);
+                    const int k = (t0 + tl) * a.cin_tap + ct * 64 + wj * 32 + (lane & 31);
+                    out[(long long)n * a.ktot + k] = acc[ni][tl][r];
+                }
+            }
+        }
+}
+
 // Sum the split slabs, apply mask and 1/grad_scale, write fp32 OIHW.  Deterministic: thread
 // (item, sg) sums the splits s = sg, sg+SG, ... in order, the SG partial sums are combined in
 // order through LDS.  SG grows with the split count so narrow layers (few weights, ~1000 pixel
@@ -534,9 +741,22 @@ static WgradPlan wgrad9_plan(long long P, int cout, int cin_tap, int W) {
     p.n_otiles = p.rows_pad / 64;
     p.n_ctiles = cin_tap / 64;
     p.n_tapgroups = 1;
+    // wide form (wgrad9w_kernel): 128 filters per workgroup, 8 waves, one workgroup per CU, 64 pixels per step,
+    // as many ring stages as fit the LDS
+    // measured (B = 64): 104x104 layers 0.198 -> 0.149 ms, 52x52 0.144 -> 0.135; 26x26 and 13x13 are within +-4 % (the
+    // narrow kernel already executes ~1.1 PFLOP/s of padded-pixel MFMAs there: 33 % of the rows are halo at 13x13)
+    // and conv22 (20 channel tiles) is 35 % slower, so the wide form is used from 40 pixels per row up
+    const bool wide = cout % 128 == 0 && env_int_w("MCAMD_WGRAD9W", 1) && W >= env_int_w("MCAMD_WGRAD9W_MINW", 40) &&
+                      2 * (size_t)(64 * 256 + (64 + 2 * wgrad9_S(W)) * 128) <= 160 * 1024;
+    if (wide) {
+        p.nine = 2;
+        p.tmo = 128;
+        p.kp = 64;
+        p.n_otiles = p.rows_pad / 128;
+    }
     long long tiles = (long long)p.n_otiles * p.n_ctiles;
     long long nsteps = (P + 31) / 32;
-    const long long slots = env_int_w("MCAMD_WGRAD9_SLOTS", 512);
+    const long long slots = wide ? env_int_w("MCAMD_WGRAD9W_SLOTS", 256) : env_int_w("MCAMD_WGRAD9_SLOTS", 512);
     long long cap = env_int_w("MCAMD_WGRAD9_WGS", 2048) / tiles;
     if (cap < 1) cap = 1;
     if (cap > nsteps / 8) cap = nsteps / 8 > 0 ? nsteps / 8 : 1;
@@ -588,7 +808,18 @@ int mcamd_wgrad9_launch(const WgradArgs& w, const WgradPlan& p, int W, long long
     a.nsteps_total = (int)((P + 31) / 32);
     const int R = 32 + 2 * a.S;
     const int grid = round_up_int(p.n_otiles * p.n_ctiles * p.nsplit, 8);
-    if (p.kp == 128) {
+    if (p.nine == 2) {
+        const size_t stage = (size_t)64 * 256 + (size_t)(64 + 2 * a.S) * 128;
+        const int ns = 3 * stage <= 160 * 1024 && env_int_w("MCAMD_WGRAD9W_NS", 3) >= 3 ? 3 : 2;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)wgrad9w_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)wgrad9w_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        if (ns == 3) hipLaunchKernelGGL((wgrad9w_kernel<64, 3>), dim3(grid), dim3(512), 3 * stage, st, a);
+        else hipLaunchKernelGGL((wgrad9w_kernel<64, 2>), dim3(grid), dim3(512), 2 * stage, st, a);
+    } else if (p.kp == 128) {
         const size_t lds = 2 * (size_t)(128 * 128 + (R + 96) * 128);
         static bool attr_set = false;
         if (lds > 64 * 1024 && !attr_set) {
