@@ -227,6 +227,14 @@ def test_layerwise_teacher_forced_b64_selected(dev):
     _teacher_forced(dev, YOLOV2_VOC_CFG, 64, 6, masked=False, only={1, 2, 14, 22, 23})
 
 
+@pytest.mark.parametrize("B,hw", [(2, (352, 480)), (2, (608, 608))])
+def test_layerwise_teacher_forced_yolov2_multiscale(dev, B, hw):
+    """Darknet's multi-scale training sizes (320 ... 608, step 32) and a non-square image: other image widths take
+    other kernel variants (raw-window weight gradients need W % 16 / % 32, the wide 9-tap kernel W >= 40, window
+    sizes and ring depths follow W)."""
+    _teacher_forced(dev, YOLOV2_VOC_CFG, B, 8, masked=False, hw=hw)
+
+
 def test_layerwise_teacher_forced_yolov2(dev):
     """All 23 conv blocks of YOLOv2-VOC at 416x416 (B=1): conv fwd, BN/leaky/pool/reorg fwd+bwd,
     wgrad, dgrad each within 1e-3 (2e-3 for the BN backward) of fp32 math on identical inputs."""
