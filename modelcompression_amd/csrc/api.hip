@@ -402,7 +402,7 @@ static WgradPlan wgrad_plan_for(const mcamd_conv_geom* g) {
     if (mcamd_wgrad_win_ok(g->ksize, g->stem, g->cout, cin_tap_of(g), g->W, (long long)g->B * g->H * g->W))
         return mcamd_wgrad_win_plan((long long)g->B * g->H * g->W, g->cout);
     if (mcamd_wgrad_use9(g->ksize, g->stem, g->cout, cin_tap_of(g), g->W))
-        return mcamd_wgrad_plan9((long long)g->B * (g->H + 2) * (g->W + 2), g->cout, cin_tap_of(g), g->W);
+        return mcamd_wgrad_plan9((long long)g->B * (g->H + 2) * (g->W + 2), g->cout, cin_tap_of(g), g->W, g->H, g->B);
     return mcamd_wgrad_plan((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g), ntaps_of(g));
 }
 

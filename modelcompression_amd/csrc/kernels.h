@@ -76,7 +76,7 @@ struct WgradArgs {
 
 struct WgradPlan {
     int tmo, tnc, taps, kp, rows_pad, n_otiles, n_ctiles, n_tapgroups, nsplit, pix_per_split;
-    int nine;   // 1: padded-pixel 9-tap kernel (wgrad9_kernel)
+    int nine;   // 1: padded-pixel 9-tap kernel (wgrad9_kernel), 2: its wide form (wgrad9w_kernel), 3: interior-pixel form (wgrad9i_kernel)
     int stemw;  // 1: raw-window first-layer kernel (wgrad_stem_kernel), 2: raw-window 32-channel kernel (wgrad_win_kernel)
     size_t bytes;
 };
@@ -95,7 +95,7 @@ bool mcamd_wgrad_win_ok(int ksize, int stem, int cout, int cin_tap, int W, long 
 WgradPlan mcamd_wgrad_win_plan(long long M, int cout);
 int mcamd_wgrad_win_launch(WgradArgs& a, const WgradPlan& p, hipStream_t st);
 bool mcamd_wgrad_use9(int ksize, int stem, int cout, int cin_tap, int W);
-WgradPlan mcamd_wgrad_plan9(long long P, int cout, int cin_tap, int W);
+WgradPlan mcamd_wgrad_plan9(long long P, int cout, int cin_tap, int W, int H, int B);
 int mcamd_wgrad9_launch(const WgradArgs& w, const WgradPlan& p, int W, long long P, hipStream_t st);
 int mcamd_wgrad_finish_launch(const float* slab, const WgradPlan& p, int ktot, int cin_tap, int stem, int Cout, int Cin,
                               int ksize, const float* mask, float inv_scale, float* dw, const int* rmap, const int* cmap,

@@ -145,10 +145,12 @@ def test_conv_fwd_padded_epilogue(dev):
     assert halo_is_zero(dst, B, H, W, 128)
 
 
+@pytest.mark.parametrize("minw", ["8", "40"])               # wide 9-tap kernel on the small test images | interior-pixel form
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_dgrad_wgrad(dev, case, monkeypatch):
+def test_conv_dgrad_wgrad(dev, case, minw, monkeypatch):
     monkeypatch.setenv("MCAMD_SMALL3X3", "2")
-    monkeypatch.setenv("MCAMD_WGRAD9W_MINW", "8")            # the wide 9-tap kernel also on the small test images
+    monkeypatch.setenv("MCAMD_WGRAD9W_MINW", minw)
+    monkeypatch.setenv("MCAMD_WGRAD9I", "1" if minw == "40" else "0")
     B, H, W, cin, cout, k = case
     x, w = _rand_case(*case, seed=11)
     gen = torch.Generator().manual_seed(12)
