@@ -24,6 +24,7 @@ SOURCES = {
     "conv_igemm_pp.hip": [],
     "conv_stem.hip": [],
     "conv_small.hip": [],
+    "conv_win.hip": [],
     "conv_wgrad.hip": [],
     "conv_wgrad_stem.hip": [],
     "bn_act.hip": [],

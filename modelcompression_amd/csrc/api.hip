@@ -298,6 +298,10 @@ extern "C" int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int
         out[0] = 128, out[1] = 128, out[2] = 64, out[3] = 9;   // igemm9_kernel (padded-pixel 9-tap)
         return MCAMD_OK;
     }
+    if (dgrad && mcamd_win3x3_shape((long long)g->B * g->H * g->W, g->cin, cout_p_of(g), g->ksize * g->ksize * cout_p_of(g), g->W)) {
+        out[0] = 32, out[1] = round_up_int(g->cin, 16), out[2] = 64, out[3] = 5;   // win3x3_kernel (conv_win.hip)
+        return MCAMD_OK;
+    }
     mcamd_igemm_tile((long long)g->B * g->H * g->W, dgrad ? g->cin : g->cout, dgrad ? cout_p_of(g) : cin_tap_of(g),
                      dgrad ? g->ksize * g->ksize * cout_p_of(g) : ntaps_of(g) * cin_tap_of(g), out);
     return MCAMD_OK;

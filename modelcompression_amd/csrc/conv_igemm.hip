@@ -429,6 +429,7 @@ static void launch_one(const IgemmArgs& a, int rows, int ntiles, hipStream_t st)
 
 // a.* geometry fields must be filled by the caller; picks the tile and launches.
 int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st) {
+    if (mcamd_win3x3_ok(a)) return mcamd_win3x3_launch(a, st);   // conv2 dgrad: rolling LDS window (conv_win.hip)
     TileCfg t = pick_tile(a.M, a.N, a.cin_tap, a.ktot, a.mode == MCAMD_EPI_RAW_F16);   // stats slabs only exist with RAW
     if (t.kind == 4) return mcamd_small3x3_launch(a, st);
     if (a.cin_tap % t.bk != 0 || a.ktot % t.bk != 0) {

@@ -103,6 +103,9 @@ int mcamd_wgrad_finish_launch(const float* slab, const WgradPlan& p, int ktot, i
 int mcamd_colsum_launch(const half_t* dy, long long rows, int ld, int choff, int C, float inv_scale, float* out,
                         hipStream_t st);
 
+bool mcamd_win3x3_ok(const IgemmArgs& a);                             // conv_win.hip
+bool mcamd_win3x3_shape(long long M, int n, int cin_tap, int ktot, int W);
+int mcamd_win3x3_launch(const IgemmArgs& a, hipStream_t st);
 bool mcamd_small3x3_ok(long long M, int n, int cin_tap, int ktot);   // conv_small.hip
 int mcamd_small3x3_rows(long long M);
 int mcamd_small3x3_launch(const IgemmArgs& a, hipStream_t st);

@@ -32,12 +32,14 @@ CONV_CASES = [
     (2, 48, 50, 64, 32, 3),       # small3x3_kernel<64, 1> forward, <32, 2> dgrad
     (3, 40, 48, 32, 64, 3),       # wgrad_win_kernel<2> (W % 16 == 0, 32 input channels)
     (2, 50, 64, 24, 32, 3),       # wgrad_win_kernel<1>, padded input channels
+    (4, 128, 144, 32, 64, 3),     # dgrad: win3x3_kernel<2> (rolling LDS window), last strip of a row 16 pixels wide
+    (2, 168, 208, 24, 48, 3),     # dgrad: win3x3_kernel<2> with 24 of 32 output channels, 48 of 64 dY channels, ragged row segments
 ]
 
 
 def test_small3x3_kernel_is_selected(dev, monkeypatch):
     monkeypatch.setenv("MCAMD_SMALL3X3", "2")                # also the 64-channel-input variants (off by default)
-    for (B, H, W, cin, cout, k) in CONV_CASES[-5:-2]:
+    for (B, H, W, cin, cout, k) in CONV_CASES[-7:-4]:
         g = ops.geom(B, H, W, k, cin, cout, ops.round_up(cin, 32))
         assert ops.tile_info(g)[3] == 4 and ops.tile_info(g, dgrad=True)[3] == 4
     g = ops.geom(2, 48, 48, 3, 64, 64, 64)                  # 72 weight fragments: generic kernel
@@ -45,6 +47,9 @@ def test_small3x3_kernel_is_selected(dev, monkeypatch):
     monkeypatch.setenv("MCAMD_SMALL3X3", "1")
     g = ops.geom(2, 48, 48, 3, 32, 64, 32)
     assert ops.tile_info(g)[3] == 4 and ops.tile_info(g, dgrad=True)[3] != 4
+    for (B, H, W, cin, cout, k) in CONV_CASES[-2:]:
+        g = ops.geom(B, H, W, k, cin, cout, 32)
+        assert ops.tile_info(g, dgrad=True)[3] == 5
 
 
 def _rand_case(B, H, W, cin, cout, k, seed=0):
