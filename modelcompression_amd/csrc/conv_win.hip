@@ -170,7 +170,22 @@ bool mcamd_win3x3_shape(long long M, int n, int cin_tap, int ktot, int W) {   //
 
 int mcamd_win3x3_launch(const IgemmArgs& a, hipStream_t st) {
     const int nstrips = (a.W + 31) / 32;
-    const int nseg = (a.H + 15) / 16, seg_rows = (a.H + nseg - 1) / nseg;      // segments of <= 16 rows
+    // Row segments: a wave runs `rounds` units of seg_rows + 4 staged rows (4 = the taps' halo + the look-ahead of the
+    // prologue).  Pick the segment length whose units fill whole rounds of the 1024 waves (208 rows, 64 images, 7
+    // strips: 13 rows -> exactly 7 units per wave, 0.150 ms; 16 rows -> 5.7, 0.165 ms).
+    const char* es = getenv("MCAMD_WIN3X3_SEG");
+    int want = es && atoi(es) > 0 ? atoi(es) : 0;
+    if (!want) {
+        const long long per_row_units = (long long)(a.M / (a.H * a.W)) * nstrips;
+        double best = 1e30;
+        for (int sg = 8; sg <= 32; ++sg) {
+            const int ns = (a.H + sg - 1) / sg, rows = (a.H + ns - 1) / ns;
+            const long long rounds = (per_row_units * ns + 1023) / 1024;
+            const double cost = (double)rounds * (rows + 4);
+            if (cost < best - 1e-9) best = cost, want = sg;
+        }
+    }
+    const int nseg = (a.H + want - 1) / want, seg_rows = (a.H + nseg - 1) / nseg;
     const long long units = (long long)(a.M / (a.H * a.W)) * nstrips * nseg;
     long long wgs = (units + 3) / 4;
     const int grid = (int)(wgs < 256 ? wgs : 256);                             // one workgroup per CU (124 KB of LDS)
