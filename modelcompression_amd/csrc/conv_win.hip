@@ -92,10 +92,20 @@ __global__ __launch_bounds__(256, 1) void win3x3_kernel(IgemmArgs a, int seg_row
         for (int h = h_lo; h < h_hi; ++h) {
             stage_row(rowptr(h + 2 + LA), slot_in);
             slot_in = slot_in + 1 == NR ? 0 : slot_in + 1;
-            // row h + 2 must have landed: behind it are LA rows of 5 DMA instructions and the stores of the LA
-            // previous output rows (ngroups each; fewer in the first rows of a unit: waiting for more is safe)
-            if (ngroups == 2) wait_vmc<5 * LA + 2 * LA>();
-            else wait_vmc<5 * LA + LA>();
+            // row h + 2 must have landed: behind it are LA rows of 5 DMA instructions and the stores of the output
+            // rows computed since it was issued (ngroups each) -- none in a unit's first row, one row's worth in its
+            // second, LA rows' worth from then on.  (Counting stores that were never issued would let the wait pass
+            // before the row is in: wrong results under load, B = 64.)
+            static_assert(LA == 2, "the three cases below are written out for LA = 2");
+            const int k = h - h_lo;
+            if (k == 0) wait_vmc<10>();
+            else if (k == 1) {
+                if (ngroups == 2) wait_vmc<12>();
+                else wait_vmc<11>();
+            } else {
+                if (ngroups == 2) wait_vmc<14>();
+                else wait_vmc<12>();
+            }
             int s1 = slot0 + 1, s2 = slot0 + 2;
             if (s1 >= NR) s1 -= NR;
             if (s2 >= NR) s2 -= NR;

@@ -224,7 +224,9 @@ def test_layerwise_teacher_forced_nonsquare_odd_batch(dev):
 def test_layerwise_teacher_forced_b64_selected(dev):
     """The bench's batch (B=64: 11 M output pixels in conv1, 0.7 GB tensors) on selected layers --
     guards the 32/64-bit index arithmetic of every kernel at real sizes."""
-    _teacher_forced(dev, YOLOV2_VOC_CFG, 64, 6, masked=False, only={1, 2, 14, 22, 23})
+    # (it also catches what small problems cannot: the vmcnt arithmetic of the free-running LDS-DMA kernels only
+    # fails when the DMA is slow, i.e. under the memory load of the full batch)
+    _teacher_forced(dev, YOLOV2_VOC_CFG, 64, 6, masked=False, only={1, 2, 3, 6, 14, 22, 23})
 
 
 @pytest.mark.parametrize("B,hw", [(2, (352, 480)), (2, (608, 608))])
