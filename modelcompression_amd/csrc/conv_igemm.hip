@@ -392,8 +392,9 @@ void mcamd_igemm_tile(long long M, int n, int cin_tap, int ktot, int out[4]) {
 static int igemm_mtiles(long long M, int bm) { return (int)((M + bm - 1) / bm); }
 
 // Number of persistent workgroups along M (== rows of the BN-statistics slab).
-int mcamd_igemm_rows(long long M, int n, int cin_tap, int ktot) {
-    TileCfg t = pick_tile(M, n, cin_tap, ktot);
+int mcamd_igemm_rows(long long M, int n, int cin_tap, int ktot, bool raw_epilogue) {
+    if (raw_epilogue && mcamd_win3x3_fwd_shape(M, n, cin_tap, ktot)) return mcamd_win3x3_fwd_rows();
+    TileCfg t = pick_tile(M, n, cin_tap, ktot, raw_epilogue);
     int ntiles = (n + t.bn - 1) / t.bn;
     int mtiles = igemm_mtiles(M, t.bm);
     if (t.kind == 4) return mcamd_small3x3_rows(M);
@@ -438,7 +439,7 @@ int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st) {
     }
     int ntiles = (a.N + t.bn - 1) / t.bn;
     a.num_mtiles = igemm_mtiles(a.M, t.bm);
-    int rows = mcamd_igemm_rows(a.M, a.N, a.cin_tap, a.ktot);
+    int rows = mcamd_igemm_rows(a.M, a.N, a.cin_tap, a.ktot, a.mode == MCAMD_EPI_RAW_F16);
     a.num_pslots = rows;
     a.num_ntiles = ntiles;
     a.xcd_order = env_int("MCAMD_XCD_ORDER", 1);

@@ -29,7 +29,12 @@ __device__ __forceinline__ void wait_vmc() {
 }
 }  // namespace
 
-template <int NB>   // 16-channel output blocks (1 | 2); 64 input channels per tap
+// QUAD = false: every wave has its own units and computes all (<= 32) output channels: the input gradient of conv2.
+// QUAD = true: the four waves of a workgroup walk the SAME units and wave w computes output channels [32 w, 32 w + 32)
+// of 128 (forward of conv3/conv5: 64 -> 128 channels at 104x104); each wave still stages its own copy of the window (the
+// four copies are fetched at about the same time and come from L1/L2), BatchNorm partial sums are taken in the store
+// pass and every wave writes its own 32 columns of the workgroup's slab row (no cross-wave reduction).
+template <int NB, bool QUAD>   // 16-channel output blocks per wave (1 | 2); 64 input channels per tap
 __global__ __launch_bounds__(256, 1) void win3x3_kernel(IgemmArgs a, int seg_rows, int nseg, int nstrips) {
     constexpr int CT = 64, KK = 2, NC = NB * 16, PXB = CT * 2;      // bytes per pixel in the ring
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -38,8 +43,9 @@ __global__ __launch_bounds__(256, 1) void win3x3_kernel(IgemmArgs a, int seg_row
     char* ring = smem + wave * (NR * ROW_BYTES + 1024);
     half_t* tile = (half_t*)(ring + NR * ROW_BYTES);                // [16 pixels][NC channels] of this wave
     const int pl = lane & 15, kg = lane >> 4;
+    const int n0 = QUAD ? wave * NC : 0;                            // first output channel of this wave
 
-    // weights: A fragment (row n = nb*16 + lane & 15, k = t*64 + 32 kk + 8 kg .. +7)
+    // weights: A fragment (row n = n0 + nb*16 + lane & 15, k = t*64 + 32 kk + 8 kg .. +7)
     h8_t wf[9][KK][NB];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -47,7 +53,7 @@ __global__ __launch_bounds__(256, 1) void win3x3_kernel(IgemmArgs a, int seg_row
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
-                wf[t][kk][nb] = *(const h8_t*)(a.w + (long long)(nb * 16 + pl) * a.ktot + t * CT + 32 * kk + 8 * kg);
+                wf[t][kk][nb] = *(const h8_t*)(a.w + (long long)(n0 + nb * 16 + pl) * a.ktot + t * CT + 32 * kk + 8 * kg);
 
     // DMA roles: piece = it*64 + lane -> pixel piece / 8, 16-byte chunk piece % 8; pieces past 271 repeat the last one
     long long src_off[5];
@@ -64,8 +70,13 @@ __global__ __launch_bounds__(256, 1) void win3x3_kernel(IgemmArgs a, int seg_row
     };
     const int b_off = pl * PXB + kg * 16;                           // lane's place inside a 16-pixel group of a ring row
 
+    float bs1[8], bs2[8];                                           // BatchNorm partial sums of this lane's 8 channels (QUAD)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs1[e] = bs2[e] = 0.f;
+    const bool want_stats = QUAD && a.stats != nullptr;
+
     const int nunits = a.M / (a.H * a.W) * nstrips * nseg;
-    const int nwaves = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
+    const int nwaves = QUAD ? gridDim.x : gridDim.x * 4, gw = QUAD ? blockIdx.x : blockIdx.x * 4 + wave;
     for (int unit = gw; unit < nunits; unit += nwaves) {
         const int seg = unit % nseg, rest = unit / nseg;
         const int strip = rest % nstrips, b = rest / nstrips;
@@ -73,7 +84,7 @@ __global__ __launch_bounds__(256, 1) void win3x3_kernel(IgemmArgs a, int seg_row
         int h_hi = h_lo + seg_rows;
         if (h_hi > a.H) h_hi = a.H;
         const int c0 = strip * 32;
-        const int ngroups = (a.W - c0 >= 32) ? 2 : 1;               // the last strip of a row may be 16 pixels wide
+        const int ngroups = (a.W - c0 > 16) ? 2 : 1;                // the last strip of a row may be narrower
         // padded row r of this strip starts at padded pixel (b, r, c0)
         const half_t* xs = a.x + (long long)b * a.x_img_stride + (long long)c0 * a.x_ld + a.x_off;
         auto rowptr = [&](int r) {
@@ -88,7 +99,7 @@ __global__ __launch_bounds__(256, 1) void win3x3_kernel(IgemmArgs a, int seg_row
             slot_in = slot_in + 1 == NR ? 0 : slot_in + 1;
         }
         int slot0 = 0;                                               // ring slot of padded row h (top tap row)
-        half_t* yrow = (half_t*)a.y + ((long long)(b * a.H + h_lo) * a.W + c0) * a.y_ld + a.y_choff;
+        half_t* yrow = (half_t*)a.y + ((long long)(b * a.H + h_lo) * a.W + c0) * a.y_ld + a.y_choff + n0;
         for (int h = h_lo; h < h_hi; ++h) {
             stage_row(rowptr(h + 2 + LA), slot_in);
             slot_in = slot_in + 1 == NR ? 0 : slot_in + 1;
@@ -147,7 +158,17 @@ __global__ __launch_bounds__(256, 1) void win3x3_kernel(IgemmArgs a, int seg_row
                 if (lane < 16 * RC) {
                     const int prow = lane / RC, pc = lane - prow * RC;
                     const h8_t v = *(const h8_t*)(tile + prow * NC + pc * 8);
-                    if (pc * 8 < a.N) *(h8_t*)(yrow + (long long)(gi * 16 + prow) * a.y_ld + pc * 8) = v;
+                    if (n0 + pc * 8 < a.N && c0 + gi * 16 + prow < a.W) {     // (a ragged last group of a row)
+                        *(h8_t*)(yrow + (long long)(gi * 16 + prow) * a.y_ld + pc * 8) = v;
+                        if (want_stats) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float f = (float)v[e];
+                                bs1[e] += f;
+                                bs2[e] += f * f;
+                            }
+                        }
+                    }
                 }
             };
             h8_t xf0[9][KK], xf1[9][KK];
@@ -162,27 +183,68 @@ __global__ __launch_bounds__(256, 1) void win3x3_kernel(IgemmArgs a, int seg_row
         }
         wait_vmc<0>();     // the look-ahead rows of this unit must not land in the next unit's ring
     }
+    if (want_stats) {
+        constexpr int RC = NC / 8;                                   // lanes with the same lane % RC hold the same 8 channels
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v1 = bs1[e], v2 = bs2[e];
+#pragma unroll
+            for (int msk = RC; msk < 64; msk <<= 1) {
+                v1 += __shfl_xor(v1, msk);
+                v2 += __shfl_xor(v2, msk);
+            }
+            if (lane < RC) {
+                a.stats[((long long)blockIdx.x * 2 + 0) * a.stats_ld + n0 + lane * 8 + e] = v1;
+                a.stats[((long long)blockIdx.x * 2 + 1) * a.stats_ld + n0 + lane * 8 + e] = v2;
+            }
+        }
+    }
 }
 
-// dgrad-shaped problems: 3x3, 64 padded input channels, <= 32 outputs, raw fp16 epilogue without statistics
+// dgrad-shaped problems: 3x3, 64 padded input channels, <= 32 outputs, raw fp16 epilogue without statistics;
+// forward-shaped: 64 -> 128 channels, raw fp16 epilogue with or without statistics (one slab row per workgroup)
+static bool win_enabled() {
+    const char* e = getenv("MCAMD_WIN3X3");
+    return !(e && atoi(e) == 0);
+}
+
+// OFF by default: conv3/conv5 forward 0.183 ms against 0.170 ms for the 128x128 implicit GEMM -- the window kernel's
+// per-row sequence (DMA wait, 36 fragment reads, 72 MFMAs, stores; one wave per SIMD) tops out near 700 TFLOP/s,
+// which beats the alternatives on conv2's dgrad (0.25 / 0.35 ms) but not a layer whose GEMM already runs at 600.
+bool mcamd_win3x3_fwd_shape(long long M, int n, int cin_tap, int ktot) {
+    const char* e = getenv("MCAMD_WIN3X3_FWD");
+    if (!win_enabled() || !(e && atoi(e) == 1)) return false;
+    return ktot == 9 * 64 && cin_tap == 64 && n == 128 && M >= 65536;
+}
+
+int mcamd_win3x3_fwd_rows() { return 256; }    // workgroups = rows of the statistics slab
+
 bool mcamd_win3x3_ok(const IgemmArgs& a) {
-    const char* e = getenv("MCAMD_WIN3X3");
-    if (e && atoi(e) == 0) return false;
-    return a.mode == MCAMD_EPI_RAW_F16 && !a.stats && !a.bias && a.ktot == 9 * 64 && a.cin_tap == 64 && a.kb == 64 && a.N % 8 == 0 &&
-           a.N <= 32 && a.W % 16 == 0 && a.W >= 32 && a.H >= 8 && a.M >= 65536 && a.M % (a.H * a.W) == 0;
+    if (!win_enabled()) return false;
+    if (a.mode != MCAMD_EPI_RAW_F16 || a.bias || a.kb != 64 || a.W < 32 || a.H < 8 || a.M % (a.H * a.W) != 0) return false;
+    if (mcamd_win3x3_fwd_shape(a.M, a.N, a.cin_tap, a.ktot)) return true;
+    return !a.stats && a.ktot == 9 * 64 && a.cin_tap == 64 && a.N % 8 == 0 && a.N <= 32 && a.W % 16 == 0 && a.M >= 65536;
 }
 
-bool mcamd_win3x3_shape(long long M, int n, int cin_tap, int ktot, int W) {   // for mcamd_conv_tile_info
-    const char* e = getenv("MCAMD_WIN3X3");
-    if (e && atoi(e) == 0) return false;
+bool mcamd_win3x3_shape(long long M, int n, int cin_tap, int ktot, int W) {   // for mcamd_conv_tile_info (dgrad)
+    if (!win_enabled()) return false;
     return ktot == 9 * 64 && cin_tap == 64 && n % 8 == 0 && n <= 32 && W % 16 == 0 && W >= 32 && M >= 65536;
 }
 
+template <int NB, bool QUAD>
+static void launch_win3(const IgemmArgs& a, int grid, size_t lds, int seg_rows, int nseg, int nstrips, hipStream_t st) {
+    static bool set = false;
+    if (!set) (void)hipFuncSetAttribute((const void*)win3x3_kernel<NB, QUAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), set = true;
+    hipLaunchKernelGGL((win3x3_kernel<NB, QUAD>), dim3(grid), dim3(256), lds, st, a, seg_rows, nseg, nstrips);
+}
+
 int mcamd_win3x3_launch(const IgemmArgs& a, hipStream_t st) {
+    const bool quad = a.N == 128;
     const int nstrips = (a.W + 31) / 32;
     // Row segments: a wave runs `rounds` units of seg_rows + 4 staged rows (4 = the taps' halo + the look-ahead of the
     // prologue).  Pick the segment length whose units fill whole rounds of the 1024 waves (208 rows, 64 images, 7
-    // strips: 13 rows -> exactly 7 units per wave, 0.150 ms; 16 rows -> 5.7, 0.165 ms).
+    // strips: 13 rows -> exactly 7 units per wave, 0.150 ms; 16 rows -> 5.7, 0.165 ms).  QUAD: 256 workgroups.
+    const long long runners = quad ? 256 : 1024;
     const char* es = getenv("MCAMD_WIN3X3_SEG");
     int want = es && atoi(es) > 0 ? atoi(es) : 0;
     if (!want) {
@@ -190,25 +252,21 @@ int mcamd_win3x3_launch(const IgemmArgs& a, hipStream_t st) {
         double best = 1e30;
         for (int sg = 8; sg <= 32; ++sg) {
             const int ns = (a.H + sg - 1) / sg, rows = (a.H + ns - 1) / ns;
-            const long long rounds = (per_row_units * ns + 1023) / 1024;
+            const long long rounds = (per_row_units * ns + runners - 1) / runners;
             const double cost = (double)rounds * (rows + 4);
             if (cost < best - 1e-9) best = cost, want = sg;
         }
     }
     const int nseg = (a.H + want - 1) / want, seg_rows = (a.H + nseg - 1) / nseg;
     const long long units = (long long)(a.M / (a.H * a.W)) * nstrips * nseg;
-    long long wgs = (units + 3) / 4;
-    const int grid = (int)(wgs < 256 ? wgs : 256);                             // one workgroup per CU (124 KB of LDS)
     const size_t lds = 4 * (size_t)(NR * ROW_BYTES + 1024);
-    const int nb = (a.N + 15) / 16;
-    if (nb == 1) {
-        static bool set1 = false;
-        if (!set1) (void)hipFuncSetAttribute((const void*)win3x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), set1 = true;
-        hipLaunchKernelGGL(win3x3_kernel<1>, dim3(grid), dim3(256), lds, st, a, seg_rows, nseg, nstrips);
+    if (quad) {
+        launch_win3<2, true>(a, mcamd_win3x3_fwd_rows(), lds, seg_rows, nseg, nstrips, st);
     } else {
-        static bool set2 = false;
-        if (!set2) (void)hipFuncSetAttribute((const void*)win3x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), set2 = true;
-        hipLaunchKernelGGL(win3x3_kernel<2>, dim3(grid), dim3(256), lds, st, a, seg_rows, nseg, nstrips);
+        long long wgs = (units + 3) / 4;
+        const int grid = (int)(wgs < 256 ? wgs : 256);                         // one workgroup per CU (124 KB of LDS)
+        if ((a.N + 15) / 16 == 1) launch_win3<1, false>(a, grid, lds, seg_rows, nseg, nstrips, st);
+        else launch_win3<2, false>(a, grid, lds, seg_rows, nseg, nstrips, st);
     }
     MCAMD_LAUNCH_CHECK("win3x3");
     return MCAMD_OK;

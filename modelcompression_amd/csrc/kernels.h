@@ -83,7 +83,7 @@ struct WgradPlan {
 
 void mcamd_igemm_tile(long long M, int n, int cin_tap, int ktot, int out[4]);   // {BM, BN, BK, kind}: kind 0 igemm_kernel, 2 igemm_pp_kernel
 int mcamd_igemm_pp_launch(const IgemmArgs& a, int bm, int bn, int rows, int ntiles, hipStream_t st);
-int mcamd_igemm_rows(long long M, int n, int cin_tap, int ktot);
+int mcamd_igemm_rows(long long M, int n, int cin_tap, int ktot, bool raw_epilogue = true);
 int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st);
 
 WgradPlan mcamd_wgrad_plan(long long M, int cout, int cin_tap, int ntaps);
@@ -105,6 +105,8 @@ int mcamd_colsum_launch(const half_t* dy, long long rows, int ld, int choff, int
 
 bool mcamd_win3x3_ok(const IgemmArgs& a);                             // conv_win.hip
 bool mcamd_win3x3_shape(long long M, int n, int cin_tap, int ktot, int W);
+bool mcamd_win3x3_fwd_shape(long long M, int n, int cin_tap, int ktot);
+int mcamd_win3x3_fwd_rows();
 int mcamd_win3x3_launch(const IgemmArgs& a, hipStream_t st);
 bool mcamd_small3x3_ok(long long M, int n, int cin_tap, int ktot);   // conv_small.hip
 int mcamd_small3x3_rows(long long M);

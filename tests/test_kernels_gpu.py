@@ -34,12 +34,13 @@ CONV_CASES = [
     (2, 50, 64, 24, 32, 3),       # wgrad_win_kernel<1>, padded input channels
     (4, 128, 144, 32, 64, 3),     # dgrad: win3x3_kernel<2> (rolling LDS window), last strip of a row 16 pixels wide
     (2, 168, 208, 24, 48, 3),     # dgrad: win3x3_kernel<2> with 24 of 32 output channels, 48 of 64 dY channels, ragged row segments
+    (2, 184, 184, 64, 128, 3),    # forward: win3x3_kernel<2, QUAD> (wave = 32 of 128 channels), last group of a row 8 pixels wide
 ]
 
 
 def test_small3x3_kernel_is_selected(dev, monkeypatch):
     monkeypatch.setenv("MCAMD_SMALL3X3", "2")                # also the 64-channel-input variants (off by default)
-    for (B, H, W, cin, cout, k) in CONV_CASES[-7:-4]:
+    for (B, H, W, cin, cout, k) in CONV_CASES[-8:-5]:
         g = ops.geom(B, H, W, k, cin, cout, ops.round_up(cin, 32))
         assert ops.tile_info(g)[3] == 4 and ops.tile_info(g, dgrad=True)[3] == 4
     g = ops.geom(2, 48, 48, 3, 64, 64, 64)                  # 72 weight fragments: generic kernel
@@ -47,7 +48,7 @@ def test_small3x3_kernel_is_selected(dev, monkeypatch):
     monkeypatch.setenv("MCAMD_SMALL3X3", "1")
     g = ops.geom(2, 48, 48, 3, 32, 64, 32)
     assert ops.tile_info(g)[3] == 4 and ops.tile_info(g, dgrad=True)[3] != 4
-    for (B, H, W, cin, cout, k) in CONV_CASES[-2:]:
+    for (B, H, W, cin, cout, k) in CONV_CASES[-3:-1]:
         g = ops.geom(B, H, W, k, cin, cout, 32)
         assert ops.tile_info(g, dgrad=True)[3] == 5
 
@@ -76,6 +77,7 @@ def test_layout_nchw_to_padded(dev, C, ld, choff):
 def test_conv_fwd_raw_and_stats(dev, case, bk, monkeypatch):
     monkeypatch.setenv("MCAMD_BK", bk)
     monkeypatch.setenv("MCAMD_SMALL3X3", "2" if bk == "64" else "1")
+    monkeypatch.setenv("MCAMD_WIN3X3_FWD", "1" if bk == "64" else "0")     # rolling-window forward (off by default)
     B, H, W, cin, cout, k = case
     x, w = _rand_case(*case)
     xb, ld = to_padded(x.to(dev))
