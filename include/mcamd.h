@@ -70,12 +70,14 @@ typedef struct mcamd_conv_geom {
 #define MCAMD_EPI_RAW_F16 0   /* y: fp16 [M][y_ld] + optional per-channel partial sums (BN batch statistics) */
 #define MCAMD_EPI_NCHW_F32 1  /* y: fp32 [B][cout][H][W] (+ bias)  -- the model's returned logits */
 #define MCAMD_EPI_PAD_F16 2   /* y: padded NHWC fp16, leaky(acc*scale[c]+shift[c]) (inference, BN folded) */
+#define MCAMD_EPI_RAW_F32 3   /* y: fp32 [M][y_ld], the accumulators unrounded (+ optional partial sums taken from the
+                                 fp32 values) -- the "fp16x3" precision mode, see mcamd_act_desc.planes */
 typedef struct mcamd_conv_epilogue {
     int32_t mode;
-    int32_t y_ld, y_choff;     /* modes 0 and 2 */
+    int32_t y_ld, y_choff;     /* modes 0, 2 and 3 */
     void* y;
     const float* bias;         /* mode 1, may be NULL */
-    float* stats;              /* mode 0, may be NULL: fp32 [stats_rows][2][stats_ld]; row p holds the
+    float* stats;              /* modes 0 and 3, may be NULL: fp32 [stats_rows][2][stats_ld]; row p holds the
                                   per-channel sums (index 0) and sums of squares (index 1) over the pixels
                                   that persistent workgroup p processed (fixed order: deterministic) */
     int32_t stats_rows;        /* must equal mcamd_conv_stats_rows(geom) */
@@ -85,8 +87,11 @@ typedef struct mcamd_conv_epilogue {
     float slope;               /* mode 2: negative-side slope (0.1 leaky, 1.0 linear) */
 } mcamd_conv_epilogue;
 
-/* Rows of the BatchNorm partial-sum slab a forward launch of this geometry writes. */
+/* Rows of the BatchNorm partial-sum slab a forward launch of this geometry writes (epilogue mode 0). */
 int32_t mcamd_conv_stats_rows(const mcamd_conv_geom* g);
+/* The same for a given epilogue mode (MCAMD_EPI_RAW_F16 or MCAMD_EPI_RAW_F32: the fp32 epilogue only exists in
+ * the LDS-staged implicit-GEMM kernels, so the slab shape differs for the layers that otherwise take a streaming kernel). */
+int32_t mcamd_conv_stats_rows_mode(const mcamd_conv_geom* g, int32_t mode);
 
 /* Workgroup tile {BM, BN, BK, kernel} the forward (dgrad == 0) or dgrad launch of this geometry uses:
  * kernel 0 = igemm_kernel<BM,BN,..,BK,..> (one tap per K chunk), 9 = igemm9_kernel (padded-pixel 9-tap),
@@ -191,6 +196,17 @@ typedef struct mcamd_act_desc {
     int32_t mode;              /* MCAMD_DST_* for dst */
     void* dst; int32_t dst_ld, dst_choff;   /* padded NHWC fp16 at the mode's resolution */
     void* dst2; int32_t dst2_ld, dst2_choff;/* optional second copy, PLAIN resolution (route of a pooled layer) */
+    int32_t y_dtype;           /* 0: y is fp16 (MCAMD_EPI_RAW_F16), 1: y is fp32 (MCAMD_EPI_RAW_F32) */
+    int32_t planes;            /* 1 (0 is read as 1), or 3 = split storage for the "fp16x3" precision mode: the
+                                  activation v is written as the fp16 pair hi = fp16(v), lo = fp16(v - hi) plus a second
+                                  copy of hi, at channels choff + {0, 1, 2} * plane stride.  A convolution whose input
+                                  is the 3*C-channel run [hi | lo | hi] and whose packed weights are [w_hi | w_hi | w_lo]
+                                  (w_hi = fp16(w), w_lo = fp16(w - w_hi)) accumulates x_hi*w_hi + x_lo*w_hi + x_hi*w_lo
+                                  in fp32 on the fp16 MFMA path: operand rounding drops from 2^-11 to ~2^-21, which
+                                  is what the reference's fp32 F.conv2d (layers.py:60-64) needs over 23 layers for
+                                  1e-3 logits (tools/error_budget.py).  Reading channels [0, C) alone is the plain
+                                  fp16 activation. */
+    int32_t dst_plane, dst2_plane; /* plane strides (channels, multiples of 8) of dst / dst2 when planes == 3 */
     const float* border;       /* optional fp32 [16][C], NULL = none: added to the raw conv output before the
                                   affine step, row = border class of the pixel (bit 0: h == 0, bit 1: h == H-1,
                                   bit 2: w == 0, bit 3: w == W-1).  Physically slim filter-pruned models fold the
@@ -216,6 +232,8 @@ typedef struct mcamd_act_bwd_desc {
                                   zero batch variance, which would otherwise blow dY up by 1/sqrt(eps)) */
     const int32_t* chan_perm;  /* optional device int32[C]: dgamma / dbeta of physical channel c are written to
                                   index chan_perm[c] (see mcamd_bn_coeffs) */
+    int32_t y_dtype;           /* 0: y is fp16, 1: y is fp32 (and the pooled argmax is taken on unrounded activations,
+                                  as the split-storage forward keeps them) */
 } mcamd_act_bwd_desc;
 size_t mcamd_bn_act_bwd_workspace_bytes(const mcamd_act_bwd_desc* d);
 int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, size_t workspace_bytes, void* stream);

@@ -33,6 +33,7 @@ class ActDesc(C.Structure):
                 ("scale", C.c_void_p), ("shift", C.c_void_p), ("slope", C.c_float), ("mode", C.c_int32),
                 ("dst", C.c_void_p), ("dst_ld", C.c_int32), ("dst_choff", C.c_int32),
                 ("dst2", C.c_void_p), ("dst2_ld", C.c_int32), ("dst2_choff", C.c_int32),
+                ("y_dtype", C.c_int32), ("planes", C.c_int32), ("dst_plane", C.c_int32), ("dst2_plane", C.c_int32),
                 ("border", C.c_void_p)]
 
 
@@ -56,10 +57,10 @@ class ActBwdDesc(C.Structure):
                 ("g2", C.c_void_p), ("g2_ld", C.c_int32), ("g2_choff", C.c_int32),
                 ("dy", C.c_void_p), ("dy_ld", C.c_int32), ("dy_choff", C.c_int32),
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("grad_scale", C.c_float),
-                ("dy_keep", C.c_void_p), ("chan_perm", C.c_void_p)]
+                ("dy_keep", C.c_void_p), ("chan_perm", C.c_void_p), ("y_dtype", C.c_int32)]
 
 
-EPI_RAW_F16, EPI_NCHW_F32, EPI_PAD_F16 = 0, 1, 2
+EPI_RAW_F16, EPI_NCHW_F32, EPI_PAD_F16, EPI_RAW_F32 = 0, 1, 2, 3
 DST_PLAIN, DST_POOL, DST_REORG = 0, 1, 2
 
 # name -> (restype, argtypes); the complete list of symbols include/mcamd.h declares.
@@ -69,6 +70,7 @@ SIGNATURES = {
     "mcamd_arch": (C.c_char_p, []),
     "mcamd_last_error": (C.c_char_p, []),
     "mcamd_conv_stats_rows": (_I32, [C.POINTER(ConvGeom)]),
+    "mcamd_conv_stats_rows_mode": (_I32, [C.POINTER(ConvGeom), _I32]),
     "mcamd_conv_tile_info": (C.c_int, [C.POINTER(ConvGeom), _I32, C.POINTER(_I32)]),
     "mcamd_packed_elems_fwd": (_I64, [C.POINTER(ConvGeom)]),
     "mcamd_packed_elems_dgrad": (_I64, [C.POINTER(ConvGeom)]),
@@ -105,6 +107,10 @@ def lib():
             raise McamdError(
                 "libmcamd.so is missing (%s). Build it with `python -m modelcompression_amd.build`; "
                 "modelcompression_amd has no CPU/PyTorch fallback for its compute path." % LIB_PATH)
+        # torch first: PyTorch-ROCm ships its own libamdhip64 and must be the HIP runtime of this process.  Loaded
+        # the other way round, libmcamd.so binds /opt/rocm's copy and its launches go to a second runtime that
+        # never saw torch's device / streams ("no ROCm-capable device is detected").
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)          # AttributeError here = header/library mismatch

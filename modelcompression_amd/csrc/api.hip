@@ -271,6 +271,19 @@ static int fill_epilogue(IgemmArgs& a, const mcamd_conv_epilogue* e, int n_out, 
             a.shift = e->shift;
             a.slope = e->slope;
         }
+    } else if (e->mode == MCAMD_EPI_RAW_F32) {
+        MCAMD_REQUIRE(e->y_ld % 4 == 0 && e->y_choff % 4 == 0 && e->y_choff + n_out <= e->y_ld,
+                      "%s: fp32 output slice [%d, %d) does not fit y_ld %d", what, e->y_choff, e->y_choff + n_out, e->y_ld);
+        if (e->stats) {
+            // the fp32 epilogue lives in the LDS-staged implicit-GEMM kernels only (mcamd_conv_stats_rows_mode)
+            int rows = mcamd_igemm_rows(M, n_out, cin_tap, ktot, false);
+            MCAMD_REQUIRE(e->stats_rows == rows, "%s: stats_rows must be mcamd_conv_stats_rows_mode(g, 3) = %d (got %d)", what,
+                          rows, e->stats_rows);
+            MCAMD_REQUIRE(e->stats_ld >= round_up_int(n_out, 256), "%s: stats_ld must be >= %d", what,
+                          round_up_int(n_out, 256));
+            a.stats = e->stats;
+            a.stats_ld = e->stats_ld;
+        }
     } else {
         MCAMD_REQUIRE(false, "%s: bad epilogue mode %d", what, e->mode);
     }
@@ -283,6 +296,13 @@ extern "C" int32_t mcamd_conv_stats_rows(const mcamd_conv_geom* g) {
     if (mcamd_igemm9_ok(g->ksize, g->stem, g->cout, cin_tap_of(g), g->W, MCAMD_EPI_RAW_F16))
         return mcamd_igemm9_rows((long long)g->B * (g->H + 2) * (g->W + 2), g->cout);
     return mcamd_igemm_rows((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g), ntaps_of(g) * cin_tap_of(g));
+}
+
+extern "C" int32_t mcamd_conv_stats_rows_mode(const mcamd_conv_geom* g, int32_t mode) {
+    if (!g) return 0;
+    if (mode == MCAMD_EPI_RAW_F32)
+        return mcamd_igemm_rows((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g), ntaps_of(g) * cin_tap_of(g), false);
+    return mcamd_conv_stats_rows(g);
 }
 
 extern "C" int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int32_t out[4]) {

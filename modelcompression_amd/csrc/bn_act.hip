@@ -90,7 +90,7 @@ __global__ __launch_bounds__(1024) void bn_coeffs_kernel(const float* stats, int
 // forward: y(raw fp16) -> leaky(y*scale+shift) -> {plain | 2x2 max pool | reorg} -> padded NHWC
 // ------------------------------------------------------------------------------------
 struct ActArgs {
-    const half_t* y;
+    const void* y;       // fp16 or fp32 (template parameter Y32) raw conv output
     const float* scale;
     const float* shift;
     half_t* dst;
@@ -100,6 +100,7 @@ struct ActArgs {
     float slope;
     long long items;
     const float* border;  // optional [16][C]: added to the raw conv output by border class (slim models)
+    int dst_plane, dst2_plane;  // plane strides of the split (hi | lo | hi) storage, PL == 3
 };
 
 __device__ __forceinline__ void load8(const half_t* p, float* v) {
@@ -124,6 +125,28 @@ __device__ __forceinline__ void loadf8(const float* p, float* v) {
         v[4 + i] = b[i];
     }
 }
+// raw conv output, fp16 or fp32 storage
+template <bool Y32>
+__device__ __forceinline__ void load_y(const void* y, long long idx, float* v) {
+    if (Y32) loadf8((const float*)y + idx, v);
+    else load8((const half_t*)y + idx, v);
+}
+// activation store: one fp16 plane, or the split form of the "fp16x3" precision mode (include/mcamd.h,
+// mcamd_act_desc.planes): hi = fp16(v), lo = fp16(v - hi), and hi again, `plane` channels apart
+template <int PL>
+__device__ __forceinline__ void store_act(half_t* p, int plane, const float* v) {
+    h8_t hi;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hi[i] = sat_half(v[i]);
+    *(h8_t*)p = hi;
+    if (PL == 3) {
+        h8_t lo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lo[i] = (half_t)(v[i] - (float)hi[i]);   // exact difference, one rounding; |lo| <= ulp(hi)/2
+        *(h8_t*)(p + plane) = lo;
+        *(h8_t*)(p + 2 * plane) = hi;
+    }
+}
 __device__ __forceinline__ long long pad_off(int b, int h, int w, int H, int W, int ld) {
     return (((long long)b * (H + 2) + h + 1) * (W + 2) + w + 1) * ld;
 }
@@ -135,7 +158,7 @@ __device__ __forceinline__ int border_class(int h, int w, int H, int W) {
 
 // FIXED: C/8 divides 256, so a thread keeps one channel group for the whole grid-stride loop and its BN
 // coefficients stay in registers.  !FIXED: any C % 8 == 0 (slim models), coefficients re-read per item (L1/L2 hits).
-template <int MODE, bool FIXED>
+template <int MODE, bool FIXED, bool Y32, int PL>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(ActArgs a) {
     const int CH = a.C >> 3;
     int c8 = (threadIdx.x % CH) * 8;
@@ -157,7 +180,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(ActArgs a) {
             int rem = (int)(pix - (long long)b * a.H * a.W);
             int h = rem / a.W, w = rem - h * a.W;
             float v[8];
-            load8(a.y + pix * a.y_ld + a.y_choff + c8, v);
+            load_y<Y32>(a.y, pix * a.y_ld + a.y_choff + c8, v);
             if (a.border) {
                 float bb[8];
                 loadf8(a.border + border_class(h, w, a.H, a.W) * a.C + c8, bb);
@@ -169,7 +192,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(ActArgs a) {
                 float z = v[i] * sc[i] + sh[i];
                 v[i] = z > 0.f ? z : z * a.slope;
             }
-            store8(a.dst + pad_off(b, h, w, a.H, a.W, a.dst_ld) + a.dst_choff + c8, v);
+            store_act<PL>(a.dst + pad_off(b, h, w, a.H, a.W, a.dst_ld) + a.dst_choff + c8, a.dst_plane, v);
         } else {
             int b = (int)(pix / (Ho * Wo));
             int rem = (int)(pix - (long long)b * Ho * Wo);
@@ -179,7 +202,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(ActArgs a) {
             for (int k = 0; k < 4; ++k) {
                 int h = 2 * ho + (k >> 1), w = 2 * wo + (k & 1);
                 long long sp = ((long long)b * a.H + h) * a.W + w;
-                load8(a.y + sp * a.y_ld + a.y_choff + c8, act[k]);
+                load_y<Y32>(a.y, sp * a.y_ld + a.y_choff + c8, act[k]);
                 if (a.border) {
                     float bb[8];
                     loadf8(a.border + border_class(h, w, a.H, a.W) * a.C + c8, bb);
@@ -191,17 +214,17 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(ActArgs a) {
                     float z = act[k][i] * sc[i] + sh[i];
                     act[k][i] = z > 0.f ? z : z * a.slope;
                 }
-                if (a.dst2) store8(a.dst2 + pad_off(b, h, w, a.H, a.W, a.dst2_ld) + a.dst2_choff + c8, act[k]);
+                if (a.dst2) store_act<PL>(a.dst2 + pad_off(b, h, w, a.H, a.W, a.dst2_ld) + a.dst2_choff + c8, a.dst2_plane, act[k]);
             }
             long long dp = pad_off(b, ho, wo, Ho, Wo, a.dst_ld) + a.dst_choff;
             if (MODE == MCAMD_DST_POOL) {
                 float m[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) m[i] = fmaxf(fmaxf(act[0][i], act[1][i]), fmaxf(act[2][i], act[3][i]));
-                store8(a.dst + dp + c8, m);
+                store_act<PL>(a.dst + dp + c8, a.dst_plane, m);
             } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) store8(a.dst + dp + k * a.C + c8, act[k]);
+                for (int k = 0; k < 4; ++k) store_act<PL>(a.dst + dp + k * a.C + c8, a.dst_plane, act[k]);
             }
         }
     }
@@ -211,7 +234,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(ActArgs a) {
 // backward
 // ------------------------------------------------------------------------------------
 struct ActBwdArgs {
-    const half_t* y;
+    const void* y;       // fp16 or fp32 (template parameter Y32) saved raw conv output
     const float* scale;
     const float* shift;
     const float* mean;
@@ -229,7 +252,7 @@ struct ActBwdArgs {
 };
 
 // PHASE 0: per-channel sums of g_z and g_z*xhat -> slab.  PHASE 1: dy -> padded NHWC.
-template <int MODE, int PHASE>
+template <int MODE, int PHASE, bool Y32>
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(ActBwdArgs a) {
     constexpr int NP = MODE == MCAMD_DST_PLAIN ? 1 : 4;
     const int CH = a.C >> 3;
@@ -282,7 +305,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(ActBwdArgs a) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             long long sp = ((long long)b * a.H + hh[k]) * a.W + ww[k];
-            load8(a.y + sp * a.y_ld + a.y_choff + c8, yv[k]);
+            load_y<Y32>(a.y, sp * a.y_ld + a.y_choff + c8, yv[k]);
 #pragma unroll
             for (int i = 0; i < 8; ++i) zz[k][i] = yv[k][i] * sc[i] + sh[i];
         }
@@ -294,13 +317,18 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(ActBwdArgs a) {
             load8(a.g + gp * a.g_ld + a.g_choff + c8, gv);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                // argmax over the window of the activation AS STORED (fp16) by the forward pass,
-                // first maximum in (h, w) scan order -- torch's max_pool2d tie rule on those values
-                float best = (float)(half_t)(zz[0][i] > 0.f ? zz[0][i] : zz[0][i] * a.slope);
+                // argmax over the window of the activation AS STORED by the forward pass (fp16; unrounded with the
+                // split hi | lo storage that goes with an fp32 y), first maximum in (h, w) scan order -- torch's
+                // max_pool2d tie rule on those values
+                auto stored = [&](float z) {
+                    const float av = z > 0.f ? z : z * a.slope;
+                    return Y32 ? av : (float)(half_t)av;
+                };
+                float best = stored(zz[0][i]);
                 int arg = 0;
 #pragma unroll
                 for (int k = 1; k < NP; ++k) {
-                    float av = (float)(half_t)(zz[k][i] > 0.f ? zz[k][i] : zz[k][i] * a.slope);
+                    float av = stored(zz[k][i]);
                     if (av > best) {
                         best = av;
                         arg = k;
@@ -455,8 +483,21 @@ extern "C" int mcamd_bn_act_fwd(const mcamd_act_desc* d, void* stream) {
                   "bn_act_fwd: leading dimensions / channel offsets must be multiples of 8");
     MCAMD_REQUIRE(d->mode == MCAMD_DST_PLAIN || (d->H % 2 == 0 && d->W % 2 == 0), "bn_act_fwd: pool/reorg need even H, W");
     MCAMD_REQUIRE(d->mode != MCAMD_DST_PLAIN || !d->dst2, "bn_act_fwd: dst2 only with pool/reorg");
+    MCAMD_REQUIRE(d->y_dtype == 0 || d->y_dtype == 1, "bn_act_fwd: y_dtype %d (0 = fp16, 1 = fp32)", d->y_dtype);
+    const int planes = d->planes == 0 ? 1 : d->planes;
+    MCAMD_REQUIRE(planes == 1 || planes == 3, "bn_act_fwd: planes must be 1 or 3 (got %d)", d->planes);
+    if (planes == 3) {
+        const int span = d->mode == MCAMD_DST_REORG ? 4 * d->C : d->C;
+        MCAMD_REQUIRE(d->dst_plane % 8 == 0 && d->dst_plane >= span && d->dst_choff + 2 * d->dst_plane + span <= d->dst_ld,
+                      "bn_act_fwd: 3 planes of stride %d (+ offset %d, %d channels) do not fit dst_ld %d", d->dst_plane,
+                      d->dst_choff, span, d->dst_ld);
+        MCAMD_REQUIRE(!d->dst2 || (d->dst2_plane % 8 == 0 && d->dst2_plane >= d->C &&
+                                   d->dst2_choff + 2 * d->dst2_plane + d->C <= d->dst2_ld),
+                      "bn_act_fwd: 3 planes of stride %d do not fit dst2_ld %d", d->dst2_plane, d->dst2_ld);
+    }
     ActArgs a;
-    a.y = (const half_t*)d->y;
+    a.dst_plane = d->dst_plane, a.dst2_plane = d->dst2_plane;
+    a.y = d->y;
     a.scale = d->scale;
     a.shift = d->shift;
     a.dst = (half_t*)d->dst;
@@ -473,16 +514,25 @@ extern "C" int mcamd_bn_act_fwd(const mcamd_act_desc* d, void* stream) {
     a.border = d->border;
     const int CH = d->C / 8;
     const bool fixed = CH <= 256 && 256 % CH == 0;
-#define ACT_CASE(MODE_)                                                                                         \
-    do {                                                                                                        \
-        if (fixed) hipLaunchKernelGGL((bn_act_fwd_kernel<MODE_, true>), dim3(grid), dim3(256), 0, st, a);       \
-        else hipLaunchKernelGGL((bn_act_fwd_kernel<MODE_, false>), dim3(grid), dim3(256), 0, st, a);            \
+    const bool y32 = d->y_dtype == 1;
+#define ACT_INST(MODE_, FIXED_)                                                                                         \
+    do {                                                                                                                \
+        if (y32 && planes == 3) hipLaunchKernelGGL((bn_act_fwd_kernel<MODE_, FIXED_, true, 3>), dim3(grid), dim3(256), 0, st, a);       \
+        else if (y32) hipLaunchKernelGGL((bn_act_fwd_kernel<MODE_, FIXED_, true, 1>), dim3(grid), dim3(256), 0, st, a);                 \
+        else if (planes == 3) hipLaunchKernelGGL((bn_act_fwd_kernel<MODE_, FIXED_, false, 3>), dim3(grid), dim3(256), 0, st, a);        \
+        else hipLaunchKernelGGL((bn_act_fwd_kernel<MODE_, FIXED_, false, 1>), dim3(grid), dim3(256), 0, st, a);                         \
+    } while (0)
+#define ACT_CASE(MODE_)                   \
+    do {                                  \
+        if (fixed) ACT_INST(MODE_, true); \
+        else ACT_INST(MODE_, false);      \
     } while (0)
     if (d->mode == MCAMD_DST_PLAIN) ACT_CASE(MCAMD_DST_PLAIN);
     else if (d->mode == MCAMD_DST_POOL) ACT_CASE(MCAMD_DST_POOL);
     else if (d->mode == MCAMD_DST_REORG) ACT_CASE(MCAMD_DST_REORG);
     else MCAMD_REQUIRE(false, "bn_act_fwd: bad mode %d", d->mode);
 #undef ACT_CASE
+#undef ACT_INST
     MCAMD_LAUNCH_CHECK("bn_act_fwd");
     return MCAMD_OK;
 }
@@ -506,8 +556,10 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
                   "bn_act_bwd: leading dimensions / channel offsets must be multiples of 8");
     MCAMD_REQUIRE(d->mode == MCAMD_DST_PLAIN || (d->H % 2 == 0 && d->W % 2 == 0), "bn_act_bwd: pool/reorg need even H, W");
     MCAMD_REQUIRE(d->grad_scale > 0.f, "bn_act_bwd: grad_scale must be positive");
+    MCAMD_REQUIRE(d->y_dtype == 0 || d->y_dtype == 1, "bn_act_bwd: y_dtype %d (0 = fp16, 1 = fp32)", d->y_dtype);
+    const bool y32 = d->y_dtype == 1;
     ActBwdArgs a;
-    a.y = (const half_t*)d->y;
+    a.y = d->y;
     a.scale = d->scale, a.shift = d->shift, a.mean = d->mean, a.invstd = d->invstd;
     a.g = (const half_t*)d->g;
     a.g2 = (const half_t*)d->g2;
@@ -527,13 +579,18 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
     int grid = stream_grid(a.items);
     if (grid > kBwdBlocks) grid = kBwdBlocks;
     hipStream_t st = (hipStream_t)stream;
+#define BWD_INST(MODE_, PHASE)                                                                                     \
+    do {                                                                                                          \
+        if (y32) hipLaunchKernelGGL((bn_act_bwd_kernel<MODE_, PHASE, true>), dim3(grid), dim3(256), 0, st, a);    \
+        else hipLaunchKernelGGL((bn_act_bwd_kernel<MODE_, PHASE, false>), dim3(grid), dim3(256), 0, st, a);       \
+    } while (0)
 #define BWD_LAUNCH(PHASE)                                                                                         \
     if (d->mode == MCAMD_DST_PLAIN)                                                                               \
-        hipLaunchKernelGGL((bn_act_bwd_kernel<MCAMD_DST_PLAIN, PHASE>), dim3(grid), dim3(256), 0, st, a);         \
+        BWD_INST(MCAMD_DST_PLAIN, PHASE);                                                                         \
     else if (d->mode == MCAMD_DST_POOL)                                                                           \
-        hipLaunchKernelGGL((bn_act_bwd_kernel<MCAMD_DST_POOL, PHASE>), dim3(grid), dim3(256), 0, st, a);          \
+        BWD_INST(MCAMD_DST_POOL, PHASE);                                                                          \
     else if (d->mode == MCAMD_DST_REORG)                                                                          \
-        hipLaunchKernelGGL((bn_act_bwd_kernel<MCAMD_DST_REORG, PHASE>), dim3(grid), dim3(256), 0, st, a);         \
+        BWD_INST(MCAMD_DST_REORG, PHASE);                                                                         \
     else                                                                                                          \
         MCAMD_REQUIRE(false, "bn_act_bwd: bad mode %d", d->mode);
     BWD_LAUNCH(0)
@@ -544,6 +601,7 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
     BWD_LAUNCH(1)
     MCAMD_LAUNCH_CHECK("bn_act_bwd apply");
 #undef BWD_LAUNCH
+#undef BWD_INST
     return MCAMD_OK;
 }
 

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <mutex>
+
 #include "../../include/mcamd.h"
 
 typedef _Float16 half_t;
@@ -15,6 +17,18 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 #define MCAMD_WAVE 64
+
+// Opt a kernel into more than 64 KB of dynamic LDS exactly once per process.  std::call_once: the header promises
+// that the entry points are re-entrant across host threads, and a plain `static bool` flag lets a second thread
+// launch before the first one's hipFuncSetAttribute has returned.
+#define MCAMD_LDS_OPT_IN(kernel, bytes)                                                                       \
+    do {                                                                                                      \
+        static std::once_flag once_;                                                                          \
+        std::call_once(once_, [&] {                                                                           \
+            (void)hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                      (int)(bytes));                                                          \
+        });                                                                                                   \
+    } while (0)
 
 void mcamd_set_error(const char* fmt, ...);
 

@@ -217,6 +217,27 @@ void igemm_kernel(IgemmArgs a) {
                         }
                     }
                 }
+        } else if constexpr (EPI == MCAMD_EPI_RAW_F32) {
+            // unrounded accumulators, fp32 [M][y_ld]: a store instruction writes two rows x 32 consecutive floats
+            // (whole 128-byte lines straight from the registers); BN partial sums from the same fp32 values
+            float* y = (float*)a.y;
+            const int mlim = a.M - mt * BM;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = nt * BN + wn * WN + j * 32 + (lane & 31);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wm * WM + i * 32 + mfma32_row(r, lane);
+                        const float v = acc[i][j][r];
+                        if (row < mlim) {
+                            if (n < a.N) y[(long long)(mt * BM + row) * a.y_ld + a.y_choff + n] = v;
+                            s1[j] += v;
+                            s2[j] += v * v;
+                        }
+                    }
+            }
         } else {
             __syncthreads();  // every wave is done with the stage buffers
             half_t* ct = (half_t*)smem;  // [BM][BN] fp16 output tile
@@ -275,7 +296,7 @@ void igemm_kernel(IgemmArgs a) {
         }
     }
 
-    if (EPI == MCAMD_EPI_RAW_F16 && a.stats) {
+    if ((EPI == MCAMD_EPI_RAW_F16 || EPI == MCAMD_EPI_RAW_F32) && a.stats) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             s1[j] += __shfl_xor(s1[j], 32);
@@ -412,18 +433,14 @@ static void launch_inst(const IgemmArgs& a, int rows, int ntiles, hipStream_t st
     size_t lds = NSTAGE * STAGE_BYTES;
     if (lds < (size_t)BM * BN * 2) lds = (size_t)BM * BN * 2;
     if (lds < (size_t)(BM / WM) * 2 * BN * 4) lds = (size_t)(BM / WM) * 2 * BN * 4;
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, WM, WN, BK, NSTAGE, EPI>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    if (lds > 64 * 1024) MCAMD_LDS_OPT_IN((igemm_kernel<BM, BN, WM, WN, BK, NSTAGE, EPI>), lds);   // lds is a per-instance constant
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BK, NSTAGE, EPI>), dim3(round_up_int(rows, 8) * ntiles + 8), dim3(NT), lds, st, a);
 }
 
 template <int BM, int BN, int WM, int WN, int BK, int NSTAGE>
 static void launch_one(const IgemmArgs& a, int rows, int ntiles, hipStream_t st) {
     if (a.mode == MCAMD_EPI_NCHW_F32) launch_inst<BM, BN, WM, WN, BK, NSTAGE, MCAMD_EPI_NCHW_F32>(a, rows, ntiles, st);
+    else if (a.mode == MCAMD_EPI_RAW_F32) launch_inst<BM, BN, WM, WN, BK, NSTAGE, MCAMD_EPI_RAW_F32>(a, rows, ntiles, st);
     else if (a.mode == MCAMD_EPI_PAD_F16) launch_inst<BM, BN, WM, WN, BK, NSTAGE, MCAMD_EPI_PAD_F16>(a, rows, ntiles, st);
     else launch_inst<BM, BN, WM, WN, BK, NSTAGE, MCAMD_EPI_RAW_F16>(a, rows, ntiles, st);
 }

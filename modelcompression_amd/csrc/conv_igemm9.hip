@@ -195,7 +195,7 @@ static int env_i9(const char* name, int dflt) {
 
 bool mcamd_igemm9_ok(int ksize, int stem, int n, int cin_tap, int W, int mode) {
     if (!env_i9("MCAMD_IGEMM9", 0)) return false;   // measured slower than igemm_kernel at 13x13..52x52 (halo-row work): opt-in
-    if (ksize != 3 || stem || cin_tap % 64 != 0 || n % 8 != 0 || mode == MCAMD_EPI_NCHW_F32) return false;
+    if (ksize != 3 || stem || cin_tap % 64 != 0 || n % 8 != 0 || mode == MCAMD_EPI_NCHW_F32 || mode == MCAMD_EPI_RAW_F32) return false;
     if (n % 128 != 0 && n < 128) return false;
     return W <= env_i9("MCAMD_IGEMM9_MAXW", 26);
 }
@@ -221,12 +221,7 @@ int mcamd_igemm9_launch(Igemm9Args& a, hipStream_t st) {
     const int grid = round_up_int(a.num_pslots, 8) * a.num_ntiles;
 #define L9(EPI_)                                                                                                    \
     {                                                                                                               \
-        static bool attr_set = false;                                                                               \
-        if (lds > 64 * 1024 && !attr_set) {                                                                         \
-            (void)hipFuncSetAttribute((const void*)igemm9_kernel<EPI_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      160 * 1024);                                                                  \
-            attr_set = true;                                                                                        \
-        }                                                                                                           \
+        if (lds > 64 * 1024) MCAMD_LDS_OPT_IN(igemm9_kernel<EPI_>, 160 * 1024);                                     \
         hipLaunchKernelGGL((igemm9_kernel<EPI_>), dim3(grid), dim3(256), lds, st, a);                               \
     }
     if (a.mode == MCAMD_EPI_PAD_F16) L9(MCAMD_EPI_PAD_F16) else L9(MCAMD_EPI_RAW_F16)

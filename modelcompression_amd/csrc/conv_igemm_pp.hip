@@ -297,6 +297,26 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
                         }
                     }
                 }
+        } else if constexpr (EPI == MCAMD_EPI_RAW_F32) {
+            // unrounded accumulators, fp32 [M][y_ld], straight from the registers (conv_igemm.hip); statistics from fp32
+            float* y = (float*)a.y;
+            const int mlim = a.M - mt * BM;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = nt * BN + wn * WN + j * MS + (lane & (MS - 1));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < AR; ++r) {
+                        const int row = wm * WM + i * MS + SH::rowof(r, lane);
+                        const float v = acc[i][j][r];
+                        if (row < mlim) {
+                            if (n < a.N) y[(long long)(mt * BM + row) * a.y_ld + a.y_choff + n] = v;
+                            s1[j] += v;
+                            s2[j] += v * v;
+                        }
+                    }
+            }
         } else {
             __syncthreads();   // every wave is done with the stage buffers
             half_t* ct = (half_t*)smem;   // [BM][BN] fp16 output tile (128 KB)
@@ -355,7 +375,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
         }
     }
 
-    if (EPI == MCAMD_EPI_RAW_F16 && a.stats) {
+    if ((EPI == MCAMD_EPI_RAW_F16 || EPI == MCAMD_EPI_RAW_F32) && a.stats) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {   // lanes that hold the same column: l ^ 32 (and l ^ 16 for 16x16 blocks)
             s1[j] += __shfl_xor(s1[j], 32);
@@ -389,12 +409,7 @@ template <int EPI, int BM, int BN, int MS>
 static void launch_pp(const IgemmArgs& a, int rows, int ntiles, hipStream_t st) {
     constexpr size_t ring = (size_t)NST * (BM + BN) * CPR * 16;   // <= 128 KB: the ring, then the fp16 output tile
     static_assert((size_t)BM * BN * 2 <= ring, "output tile fits the ring");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)igemm_pp_kernel<EPI, BM, BN, MS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)ring);
-        attr_set = true;
-    }
+    MCAMD_LDS_OPT_IN((igemm_pp_kernel<EPI, BM, BN, MS>), ring);
     hipLaunchKernelGGL((igemm_pp_kernel<EPI, BM, BN, MS>), dim3(round_up_int(rows, 8) * ntiles + 8), dim3(NT), ring, st, a);
 }
 
@@ -419,6 +434,7 @@ int mcamd_igemm_pp_launch(const IgemmArgs& a, int bm, int bn, int rows, int ntil
         else PP_SHAPE(EPI_, 192, 128);                                     \
     } while (0)
     if (a.mode == MCAMD_EPI_NCHW_F32) PP_CASE(MCAMD_EPI_NCHW_F32);
+    else if (a.mode == MCAMD_EPI_RAW_F32) PP_CASE(MCAMD_EPI_RAW_F32);
     else if (a.mode == MCAMD_EPI_PAD_F16) PP_CASE(MCAMD_EPI_PAD_F16);
     else PP_CASE(MCAMD_EPI_RAW_F16);
 #undef PP_CASE

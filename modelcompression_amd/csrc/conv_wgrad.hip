@@ -974,21 +974,13 @@ int mcamd_wgrad9_launch(const WgradArgs& w, const WgradPlan& p, int W, long long
     } else if (p.nine == 2) {
         const size_t stage = (size_t)64 * 256 + (size_t)(64 + 2 * a.S) * 128;
         const int ns = 3 * stage <= 160 * 1024 && env_int_w("MCAMD_WGRAD9W_NS", 3) >= 3 ? 3 : 2;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)wgrad9w_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)wgrad9w_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
+        MCAMD_LDS_OPT_IN((wgrad9w_kernel<64, 2>), 160 * 1024);
+        MCAMD_LDS_OPT_IN((wgrad9w_kernel<64, 3>), 160 * 1024);
         if (ns == 3) hipLaunchKernelGGL((wgrad9w_kernel<64, 3>), dim3(grid), dim3(512), 3 * stage, st, a);
         else hipLaunchKernelGGL((wgrad9w_kernel<64, 2>), dim3(grid), dim3(512), 2 * stage, st, a);
     } else if (p.kp == 128) {
         const size_t lds = 2 * (size_t)(128 * 128 + (R + 96) * 128);
-        static bool attr_set = false;
-        if (lds > 64 * 1024 && !attr_set) {
-            (void)hipFuncSetAttribute((const void*)wgrad9_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
-            attr_set = true;
-        }
+        if (lds > 64 * 1024) MCAMD_LDS_OPT_IN(wgrad9_kernel<128>, 72 * 1024);
         hipLaunchKernelGGL(wgrad9_kernel<128>, dim3(grid), dim3(256), lds, st, a);
     } else if (p.kp == 64) {
         const size_t lds = 2 * (size_t)(64 * 128 + (R + 32) * 128);
@@ -1043,12 +1035,7 @@ WgradPlan mcamd_wgrad_plan(long long M, int cout, int cin_tap, int ntaps) {
 template <int TMo, int TNc, int TAPS, int KP>
 static void launch_w(const WgradArgs& a, int grid, hipStream_t st) {
     size_t lds = 2 * (size_t)(KP * (TMo / 8) + TAPS * KP * (TNc / 8)) * 16;
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<TMo, TNc, TAPS, KP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
-        attr_set = true;
-    }
+    if (lds > 64 * 1024) MCAMD_LDS_OPT_IN((wgrad_kernel<TMo, TNc, TAPS, KP>), lds);   // lds is a per-instance constant
     hipLaunchKernelGGL((wgrad_kernel<TMo, TNc, TAPS, KP>), dim3(grid), dim3(256), lds, st, a);
 }
 

@@ -351,11 +351,7 @@ template <int NI>
 static void launch_win(const WgradArgs& a, int grid, hipStream_t st) {
     constexpr int NS = 6;                                     // 5 stages (27 KB per wave) in flight: latency-bound below that
     const size_t lds = 4 * NS * (16 * NI * 64 + 4096);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)wgrad_win_kernel<NI, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    MCAMD_LDS_OPT_IN((wgrad_win_kernel<NI, NS>), lds);   // lds is a per-instance constant
     hipLaunchKernelGGL((wgrad_win_kernel<NI, NS>), dim3(grid), dim3(256), lds, st, a);
 }
 

@@ -233,8 +233,7 @@ bool mcamd_win3x3_shape(long long M, int n, int cin_tap, int ktot, int W) {   //
 
 template <int NB, bool QUAD>
 static void launch_win3(const IgemmArgs& a, int grid, size_t lds, int seg_rows, int nseg, int nstrips, hipStream_t st) {
-    static bool set = false;
-    if (!set) (void)hipFuncSetAttribute((const void*)win3x3_kernel<NB, QUAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), set = true;
+    MCAMD_LDS_OPT_IN((win3x3_kernel<NB, QUAD>), 160 * 1024);   // the window size follows the image width: opt in to the whole LDS
     hipLaunchKernelGGL((win3x3_kernel<NB, QUAD>), dim3(grid), dim3(256), lds, st, a, seg_rows, nseg, nstrips);
 }
 

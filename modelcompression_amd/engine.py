@@ -30,11 +30,13 @@ from ._lib import McamdError
 
 
 class _T:
-    """Where a block output lives: channel slice [choff, choff+C) of a padded NHWC buffer."""
-    __slots__ = ("buf", "ld", "choff", "C", "H", "W")
+    """Where a block output lives: channel slice [choff, choff+C) of a padded NHWC buffer.  `ps`: plane stride of
+    the buffer when it holds split (hi | lo | hi) activations (precision "fp16x3"): the slice repeats at
+    choff + ps and choff + 2 * ps."""
+    __slots__ = ("buf", "ld", "choff", "C", "H", "W", "ps")
 
-    def __init__(self, buf, ld, choff, C, H, W):
-        self.buf, self.ld, self.choff, self.C, self.H, self.W = buf, ld, choff, C, H, W
+    def __init__(self, buf, ld, choff, C, H, W, ps=0):
+        self.buf, self.ld, self.choff, self.C, self.H, self.W, self.ps = buf, ld, choff, C, H, W, ps
 
 
 class _Layer:
@@ -58,9 +60,27 @@ def _resolve_routes(blocks):
     return ops_
 
 
+# Relative error one conv block adds to the logits when both of its MFMA operands are plain fp16 (weights and
+# stored activation rounded to 11 bits: 2 x 2.07e-4 rms in quadrature; tools/error_budget.py measures 1.1-3.2e-4 per
+# block of YOLOv2-VOC, 1.26e-3 root-sum-square over the 23 blocks = the 1.3e-3 the all-fp16 forward shows).
+PLAIN_BLOCK_ERR = 2.9e-4
+# "mixed" precision keeps plain fp16 operands on the costliest blocks while their root-sum-square stays below this
+# (north_star: region-layer logits within 1e-3 of the reference; measured on YOLOv2-VOC: 5.2e-4 at B=1)
+MIXED_BUDGET = 5.5e-4
+
+
 class Engine:
-    def __init__(self, model, B, H, W, device, grad_scale=256.0):
+    def __init__(self, model, B, H, W, device, grad_scale=256.0, precision="fp16"):
+        """`precision`: "fp16" -- fp16 MFMA operands everywhere (the throughput mode); "fp16x3" -- every conv block
+        multiplies split operands (x_hi*w_hi + x_lo*w_hi + x_hi*w_lo, fp32 accumulate: three fp16 MFMA products per
+        multiply, ~2^-21 operand precision), activations are stored as hi | lo pairs and the raw conv output as fp32;
+        "mixed" -- split operands except on the costliest blocks that the 1e-3 logit budget can afford to leave
+        plain (MIXED_BUDGET).  The backward pass uses plain fp16 operands in every mode."""
+        if precision not in ("fp16", "fp16x3", "mixed"):
+            raise McamdError("precision must be 'fp16', 'fp16x3' or 'mixed' (got %r)" % (precision,))
         self.model, self.B, self.device = model, B, device
+        self.precision = precision
+        self.precise = precision != "fp16"
         self.grad_scale = float(grad_scale)
         self.serial = 0
         self._packed_sig = None
@@ -144,21 +164,24 @@ class Engine:
             self.bufs.append(ops.alloc_padded(Bn, h, w, ld, dev))
             return len(self.bufs) - 1
 
+        planes = 3 if self.precise else 1      # split (hi | lo | hi) activation storage
+
         for ind, (t, _) in enumerate(bops):
             if t == "route" and len(srcs[ind]) == 2:
                 a, b = srcs[ind]
                 (ca, h, w), (cb, _, _) = shape[a], shape[b]
                 assert ca % 8 == 0 and a not in place and b not in place
-                ld = ops.round_up(ca + cb, 32)
+                ld = ops.round_up((ca + cb) * planes, 32)
+                ps = ca + cb if self.precise else 0
                 bid = new_buf(B, h, w, ld)
-                place[a] = _T(bid, ld, 0, ca, h, w)
-                place[b] = _T(bid, ld, ca, cb, h, w)
-                place[ind] = _T(bid, ld, 0, ca + cb, h, w)
+                place[a] = _T(bid, ld, 0, ca, h, w, ps)
+                place[b] = _T(bid, ld, ca, cb, h, w, ps)
+                place[ind] = _T(bid, ld, 0, ca + cb, h, w, ps)
         cin0 = shape[-1][0]
         first_k = int(blocks[conv_inds[0] + 1]["size"])
-        self.stem = (cin0 == 3 and first_k == 3)
-        ld0 = 4 if self.stem else ops.round_up(cin0, 32)
-        place[-1] = _T(new_buf(B, H0, W0, ld0), ld0, 0, cin0, H0, W0)
+        self.stem = (cin0 == 3 and first_k == 3) and not self.precise    # NHWC4 image: plain fp16 only
+        ld0 = 4 if self.stem else ops.round_up(cin0 * planes, 32)
+        place[-1] = _T(new_buf(B, H0, W0, ld0), ld0, 0, cin0, H0, W0, cin0 if self.precise else 0)
         materialized = set()
         for ci in conv_inds:
             mode, out_id, out2_id = fused[ci]
@@ -168,8 +191,8 @@ class Engine:
                 materialized.add(tid)
                 if tid not in place and consumers.get(tid):
                     c, h, w = shape[tid]
-                    ld = ops.round_up(c, 32)
-                    place[tid] = _T(new_buf(B, h, w, ld), ld, 0, c, h, w)
+                    ld = ops.round_up(c * planes, 32)
+                    place[tid] = _T(new_buf(B, h, w, ld), ld, 0, c, h, w, c if self.precise else 0)
 
         # layers
         self.layers = []
@@ -197,6 +220,7 @@ class Engine:
                 raise NotImplementedError("conv block %d: only 'same' 1x1/3x3 convolutions" % ci)
             lay.stem = 1 if (li == 0 and self.stem) else 0
             lay.geom = ops.geom(B, lay.H, lay.W, lay.k, lay.cin, lay.cout, tin.ld, tin.choff, lay.stem)
+            lay.level = 1     # operand terms of the forward product: 1 plain, 3 = x_hi*w_hi + x_lo*w_hi + x_hi*w_lo
             lay.M = B * lay.H * lay.W
             lay.mode, lay.out_id, lay.out2_id = fused[ci]
             lay.is_last = lay.bn is None
@@ -234,11 +258,27 @@ class Engine:
                 for m in srcs[lay.src]:
                     self.consumer_of[m] = lay
 
+        if self.precise:
+            # split operands need the input tensor's three planes side by side: a channel slice of a wider buffer
+            # (no such consumer on the YOLOv2 path) stays plain
+            can = [lay for lay in self.layers if lay.tin.choff == 0 and lay.tin.C == lay.tin.ps]
+            plain = set()
+            if self.precision == "mixed":
+                budget = int((MIXED_BUDGET / PLAIN_BLOCK_ERR) ** 2)        # blocks that may keep plain operands
+                by_cost = sorted(can, key=lambda l: (-l.M * l.cout * l.cin * l.k * l.k, -l.li))
+                plain = set(l.li for l in by_cost[:max(0, budget - (len(self.layers) - len(can)))])
+            for lay in can:
+                if lay.li not in plain:
+                    lay.level = 3
         f32 = dict(dtype=torch.float32, device=dev)
         wbytes = 0
         for lay in self.layers:
             g = lay.geom
-            nf, nd = ops.packed_elems(g)
+            # forward geometry: the K-concatenated problem [x_hi | x_lo | x_hi] x [w_hi | w_hi | w_lo]
+            lay.geom_f = g if lay.level == 1 else ops.geom(B, lay.H, lay.W, lay.k, lay.level * lay.cin, lay.cout,
+                                                           lay.tin.ld, 0, 0)
+            nf, _ = ops.packed_elems(lay.geom_f)
+            _, nd = ops.packed_elems(g)
             # zero-initialised: the one-launch packer writes real entries only (pad rows / channels stay zero)
             lay.wp = torch.zeros(nf, dtype=ops.HALF, device=dev)
             lay.wd = torch.zeros(nd, dtype=ops.HALF, device=dev) if (nd and lay.li > 0) else None
@@ -253,8 +293,9 @@ class Engine:
             lay.n_act, lay.geom_act, lay.gather = lay.cout, lay.geom, False
             if not lay.is_last:
                 # zero-initialised: with filter compaction the convolution writes the kept channels only
-                lay.y = torch.zeros(lay.M * lay.cout, dtype=ops.HALF, device=dev)
-                lay.stats = torch.zeros(ops.stats_rows(g), 2, ops.round_up(lay.cout, 256), **f32)
+                lay.y = torch.zeros(lay.M * lay.cout, dtype=torch.float32 if self.precise else ops.HALF, device=dev)
+                lay.stats = torch.zeros(ops.stats_rows(lay.geom_f, L.EPI_RAW_F32 if self.precise else L.EPI_RAW_F16), 2,
+                                        ops.round_up(lay.cout, 256), **f32)
                 lay.scale, lay.shift, lay.mean, lay.invstd = (torch.empty(lay.cout, **f32) for _ in range(4))
                 lay.out_t = place.get(lay.out_id)
                 lay.out2_t = place.get(lay.out2_id) if lay.out2_id is not None else None
@@ -263,7 +304,7 @@ class Engine:
         self.wgrad_ws = torch.empty(max(wbytes, 16), dtype=torch.uint8, device=dev)
         self._mask_keys = None
         self._pack_key, self._pack_table, self._pack_keep = None, None, []
-        self.compact = os.environ.get("MCAMD_COMPACT", "1") == "1"
+        self.compact = os.environ.get("MCAMD_COMPACT", "1") == "1" and not self.precise
         self.fuse_eval = os.environ.get("MCAMD_FUSE_EVAL", "1") == "1"
         self.compact_gran = int(os.environ.get("MCAMD_COMPACT_GRAN", "0"))
         maxc = max(l.cout for l in self.layers)
@@ -333,6 +374,11 @@ class Engine:
                 lay.wp.zero_()
                 if lay.wd is not None:
                     lay.wd.zero_()
+        if self.precise:
+            self._pack_split()
+            self._packed_sig = sig
+            self.model._weights_dirty = False
+            return
         # geom_act / g_rows / g_cols: physical channel order (kept filters first, permuted inputs); identity = None
         tkey = tuple((s_[0], None if s_[2] is None else s_[2][0]) for s_ in sig)
         if tkey != self._pack_key:          # weight / mask storage moved, or the compaction changed: new job table
@@ -359,6 +405,25 @@ class Engine:
             ops.pack_many(*self._pack_table)
         self._packed_sig = sig
         self.model._weights_dirty = False
+
+    def _pack_split(self):
+        """Packings of the split-operand modes: forward = fp16 of [w_hi | w_hi | w_lo] along the input channels
+        (w_hi = fp16(w * mask), w_lo = fp16(w * mask - w_hi)), matching the [x_hi | x_lo | x_hi] activation planes;
+        dgrad = the plain fp16 packing (the backward pass multiplies plain operands)."""
+        for lay in self.layers:
+            w = lay.conv.weight.data
+            if w.dtype != torch.float32 or not w.is_contiguous():
+                raise McamdError("conv weights must be contiguous fp32 (master copy)")
+            mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
+            if lay.level == 1:
+                ops.pack_weights(lay.geom_f, w, mask, True, False, lay.wp, None)
+            else:
+                weff = w * mask if mask is not None else w
+                hi = weff.half().float()
+                parts = [hi, hi, weff - hi][:lay.level]
+                ops.pack_weights(lay.geom_f, torch.cat(parts, 1).contiguous(), None, True, False, lay.wp, None)
+            if lay.wd is not None:
+                ops.pack_weights(lay.geom, w, mask, False, True, None, lay.wd)
 
     # ------------------------------------------------------------------ filter compaction
     def _update_compaction(self):
@@ -408,7 +473,7 @@ class Engine:
                 lay.gather = perm is not None or in_perm is not None
                 lay.g_rows = perm[:n_act].to(torch.int32).contiguous() if perm is not None else None
                 lay.g_cols = in_perm.to(torch.int32).contiguous() if in_perm is not None else None
-                if lay.bn is not None:
+                if lay.bn is not None and not self.precise:
                     rows = ops.stats_rows(lay.geom_act)
                     if lay.stats.shape[0] != rows:
                         lay.stats = torch.zeros(rows, 2, lay.stats.shape[2], dtype=torch.float32, device=dev)
@@ -454,17 +519,36 @@ class Engine:
         self.pack(force=training)
         self.serial += 1
         tin = self.layers[0].tin
-        ops.nchw_to_padded(x.detach().contiguous().float(), self.bufs[tin.buf], tin.ld, tin.choff)
+        xs = x.detach().contiguous().float()
+        if self.precise:        # the image too is an MFMA operand: hi | lo | hi planes
+            hi = xs.half().float()
+            xs = torch.cat((hi, xs - hi, hi), 1).contiguous()
+        ops.nchw_to_padded(xs, self.bufs[tin.buf], tin.ld, tin.choff)
         out = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
         for lay in self.layers:
             xin = self.bufs[lay.tin.buf]
             if lay.is_last:
                 bias = lay.conv.bias.data if lay.conv.bias is not None else None
-                self._timed('fwd', lay, ops.conv_fwd_nchw, lay.geom_act, xin, lay.wp, out, bias)
+                self._timed('fwd', lay, ops.conv_fwd_nchw, lay.geom_f if self.precise else lay.geom_act, xin, lay.wp, out, bias)
                 if lay.border_map is not None:
                     out += lay.border_map
                 continue
             bn = lay.bn
+            if self.precise:
+                # unrounded fp32 raw output (+ batch statistics from the fp32 values), then BN + LeakyReLU
+                # (+ pool / reorg / route) written as hi | lo | hi planes
+                self._timed('fwd', lay, ops.conv_fwd_raw32, lay.geom_f, xin, lay.wp, lay.y, lay.cout, 0,
+                            lay.stats if training else None)
+                ops.bn_coeffs(lay.stats if training else None, lay.cout, lay.M, bn.weight.data, bn.bias.data,
+                              bn.running_mean, bn.running_var, training, lay.scale, lay.shift, lay.mean, lay.invstd,
+                              momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps)
+                t, t2 = lay.out_t, lay.out2_t
+                ops.bn_act_fwd(B, lay.H, lay.W, lay.cout, lay.y, lay.cout, 0, lay.scale, lay.shift, lay.slope, lay.mode,
+                               self.bufs[t.buf], t.ld, t.choff,
+                               self.bufs[t2.buf] if t2 is not None else None,
+                               t2.ld if t2 is not None else 0, t2.choff if t2 is not None else 0, border=lay.border,
+                               planes=3, dst_plane=t.ps, dst2_plane=t2.ps if t2 is not None else 0)
+                continue
             if (not training and self.fuse_eval and lay.mode == L.DST_PLAIN and lay.perm is None and lay.border is None
                     and lay.out2_t is None):
                 # inference: BN (running statistics) + LeakyReLU in the conv epilogue, written straight into the

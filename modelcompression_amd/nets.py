@@ -11,6 +11,8 @@ What differs: `Darknet.forward` does not call one torch module per block.  The b
 compiled into a fused HIP launch plan (engine.py) that runs on the GPU only; a CPU tensor
 raises instead of falling back to a PyTorch path.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -250,6 +252,11 @@ class Darknet(nn.Module):
         self._grad_ready_hook = None    # callable(flat_grad, lo, hi): that slice is final (overlapped all-reduce)
         self._last_flat_grad = None
         self.grad_scale = 256.0         # fp16 gradient scaling inside the engine, undone in fp32
+        # Operand precision of the forward convolutions (engine.py): "fp16" (throughput), "fp16x3" (split hi/lo
+        # operands, three fp16 MFMA products per multiply), "mixed" (split except on the costliest blocks the 1e-3
+        # logit budget leaves plain), or "auto" = "fp16" while training, "mixed" in eval mode -- so that inference
+        # reproduces the reference's fp32 region-layer logits within 1e-3 (north_star) by default.
+        self.precision = os.environ.get("MCAMD_PRECISION", "auto")
 
     # ---- engine plumbing
     def _apply(self, fn, *args, **kwargs):
@@ -267,12 +274,15 @@ class Darknet(nn.Module):
 
     def _engine_for(self, x):
         from .engine import Engine
-        key = (tuple(x.shape), x.device.index, float(self.grad_scale))
+        prec = self.precision
+        if prec == "auto":
+            prec = "fp16" if self.training else "mixed"
+        key = (tuple(x.shape), x.device.index, float(self.grad_scale), prec)
         eng = self._engines.get(key)
         if eng is None:
-            if len(self._engines) >= 2:
+            if len(self._engines) >= 3:
                 self._engines.pop(next(iter(self._engines)))
-            eng = Engine(self, x.shape[0], x.shape[2], x.shape[3], x.device, self.grad_scale)
+            eng = Engine(self, x.shape[0], x.shape[2], x.shape[3], x.device, self.grad_scale, prec)
             self._engines[key] = eng
         return eng
 

@@ -112,8 +112,9 @@ def tile_info(g, dgrad=False):
     return tuple(out)
 
 
-def stats_rows(g):
-    return int(L.lib().mcamd_conv_stats_rows(C.byref(g)))
+def stats_rows(g, mode=L.EPI_RAW_F16):
+    """Rows of the BN partial-sum slab a forward launch of `g` writes with epilogue `mode` (RAW_F16 or RAW_F32)."""
+    return int(L.lib().mcamd_conv_stats_rows_mode(C.byref(g), mode))
 
 
 def _epi(mode, y, y_ld=0, y_choff=0, bias=None, stats=None, stats_rows_=0, stats_ld=0, scale=None, shift=None,
@@ -133,6 +134,15 @@ def _epi(mode, y, y_ld=0, y_choff=0, bias=None, stats=None, stats_rows_=0, stats
 def conv_fwd_raw(g, x, wp, y, y_ld, y_choff=0, stats=None):
     """y[M][y_ld] fp16 raw conv output; `stats`: fp32 [stats_rows(g)][2][stats_ld] slab or None."""
     e = _epi(L.EPI_RAW_F16, y, y_ld, y_choff, stats=stats,
+             stats_rows_=stats.shape[0] if stats is not None else 0,
+             stats_ld=stats.shape[2] if stats is not None else 0)
+    check(L.lib().mcamd_conv_fwd(C.byref(g), ptr(x), ptr(wp), C.byref(e), stream_ptr()), "mcamd_conv_fwd")
+
+
+def conv_fwd_raw32(g, x, wp, y, y_ld, y_choff=0, stats=None):
+    """y[M][y_ld] fp32: the unrounded accumulators (the "fp16x3" precision mode); `stats` as conv_fwd_raw, with
+    stats_rows(g, EPI_RAW_F32) rows, summed from the fp32 values."""
+    e = _epi(L.EPI_RAW_F32, y, y_ld, y_choff, stats=stats,
              stats_rows_=stats.shape[0] if stats is not None else 0,
              stats_ld=stats.shape[2] if stats is not None else 0)
     check(L.lib().mcamd_conv_fwd(C.byref(g), ptr(x), ptr(wp), C.byref(e), stream_ptr()), "mcamd_conv_fwd")
@@ -191,9 +201,13 @@ def bn_coeffs(stats, C_, count, gamma, beta, rmean, rvar, training, scale, shift
 
 
 def bn_act_fwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, slope, mode, dst, dst_ld, dst_choff=0, dst2=None,
-               dst2_ld=0, dst2_choff=0, border=None):
-    """`border`: optional fp32 [16, C] table added to the raw conv output by border class (slim models)."""
+               dst2_ld=0, dst2_choff=0, border=None, planes=1, dst_plane=0, dst2_plane=0):
+    """`border`: optional fp32 [16, C] table added to the raw conv output by border class (slim models).
+    `y` may be fp16 or fp32 (conv_fwd_raw / conv_fwd_raw32).  planes=3: split (hi | lo | hi) activation storage of
+    the "fp16x3" precision mode with plane strides dst_plane / dst2_plane (include/mcamd.h, mcamd_act_desc.planes)."""
     d = ActDesc()
+    d.y_dtype = 1 if y.dtype == torch.float32 else 0
+    d.planes, d.dst_plane, d.dst2_plane = planes, dst_plane, dst2_plane
     d.B, d.H, d.W, d.C = B, H, W, C_
     d.y, d.y_ld, d.y_choff = y.data_ptr(), y_ld, y_choff
     d.scale, d.shift, d.slope, d.mode = scale.data_ptr(), shift.data_ptr(), slope, mode
@@ -224,6 +238,7 @@ def bn_act_bwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, mean, invstd, slope,
     d.grad_scale = grad_scale
     d.dy_keep = dy_keep.data_ptr() if dy_keep is not None else None
     d.chan_perm = _perm_ptr(perm, C_)
+    d.y_dtype = 1 if y.dtype == torch.float32 else 0
     need = int(L.lib().mcamd_bn_act_bwd_workspace_bytes(C.byref(d)))
     if workspace is None:
         workspace = torch.empty(need, dtype=torch.uint8, device=y.device)

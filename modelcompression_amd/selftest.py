@@ -23,25 +23,39 @@ def smoke_mini(verbose=True):
     x = torch.rand(2, 3, 64, 64, generator=g)
     gout = torch.randn(2, 125, 16, 16, generator=g)
 
-    model = nets.Darknet(MINI_CFG)
-    model.load_state_dict(state)
-    model.cuda().train()
-    out = model(x.cuda())
-    out.backward(gout.cuda())
-
     st = {k: v.clone() for k, v in state.items()}
     keys = O.param_keys(blocks)
     for k in keys:
         st[k].requires_grad_(True)
     ref = O.forward(blocks, st, x, training=True)
     ref.backward(gout)
-    e_out = rel_l2(out.detach(), ref.detach())
-    worst = 0.0
-    for (name, p) in model.named_parameters():
-        worst = max(worst, rel_l2(p.grad, st[name].grad))
-    if verbose:
-        print("smoke: logits rel-L2 %.2e, worst param-grad rel-L2 %.2e" % (e_out, worst))
-    assert e_out < 3e-3, e_out
+
+    res = {}
+    for prec in ("fp16x3", "fp16"):
+        model = nets.Darknet(MINI_CFG)
+        model.load_state_dict(state)
+        model.precision = prec
+        model.cuda().train()
+        out = model(x.cuda())
+        out.backward(gout.cuda())
+        e_out = rel_l2(out.detach(), ref.detach())
+        worst = 0.0
+        for (name, p) in model.named_parameters():
+            worst = max(worst, rel_l2(p.grad, st[name].grad))
+        res[prec] = (e_out, worst)
+        if verbose:
+            print("smoke [%s]: train logits rel-L2 %.2e, worst param-grad rel-L2 %.2e" % (prec, e_out, worst))
+    # north_star: region-layer logits within 1e-3 of the reference -- met by the split-operand forward.  The plain
+    # fp16 throughput mode is held to its storage floor (3 roundings per block, amplified by train-mode BN).
+    assert res["fp16x3"][0] < 1e-3, res
+    assert res["fp16"][0] < 3e-3, res
     # gradients through LeakyReLU kinks respond to fp16 storage as ~sqrt(eps): see tests/test_model_gpu.py
-    assert worst < 0.2, worst
-    return e_out, worst
+    assert res["fp16x3"][1] < 0.2 and res["fp16"][1] < 0.2, res
+    model.eval()          # default eval precision ("auto" -> "mixed")
+    model.precision = "auto"
+    with torch.no_grad():
+        e_eval = rel_l2(model(x.cuda()), O.forward(blocks, state, x, training=False))
+    if verbose:
+        print("smoke [eval, default precision]: logits rel-L2 %.2e" % e_eval)
+    assert e_eval < 1e-3, e_eval
+    return res["fp16x3"]

@@ -1,9 +1,11 @@
 """End-to-end GPU parity: Darknet on the HIP engine vs the oracle / golden fixtures.
 
-Tolerances (stated per north_star): conv activations and logits within 1e-3 relative
-(measured as relative L2 per tensor) given the same inputs; because activations are stored
-in fp16 between 7-23 layers the end-to-end bounds below are a small multiple of that and the
-measured values are printed.  Mask index lists are bit-exact (test_pruning_gpu.py)."""
+Tolerances (north_star): conv activations and region-layer logits within 1e-3 relative (relative L2
+per tensor) of the reference's fp32 path on the same inputs.  Plain fp16 MFMA operands cost ~2.9e-4
+per conv block (tools/error_budget.py), 1.3-1.8e-3 over YOLOv2's 23 blocks, so the eval-mode default
+("mixed" precision, engine.py) multiplies split hi/lo operands on all but the costliest blocks; every
+eval-logits test below asserts 1e-3.  The plain-fp16 throughput mode is tested against its own floor.
+Mask index lists are bit-exact (test_pruning_gpu.py)."""
 import os
 
 import numpy as np
@@ -36,7 +38,38 @@ def test_mini_eval_logits_vs_golden(dev):
         out = m(torch.from_numpy(gold["x"]).to(dev))
     e = rel_l2(out.cpu(), torch.from_numpy(gold["eval_logits"]))
     print("mini eval logits rel-L2 vs reference golden: %.2e" % e)
-    assert e < 2e-3
+    assert e < 1e-3
+
+
+def test_mini_train_fp16x3_vs_golden(dev):
+    """Training-mode forward with split operands (precision "fp16x3": fp32 raw outputs, batch statistics from the
+    fp32 values, hi | lo activation planes): train logits within 1e-3 of the reference's golden run; the backward
+    pass (plain fp16 operands on the precise activations) against the same conditioning-aware bars as the fp16 mode."""
+    gold = np.load(os.path.join(HERE, "golden", "mini_fwd_bwd.npz"))
+    m, blocks, state = _mini_model(dev)
+    m.precision = "fp16x3"
+    m.train()
+    x, gout = torch.from_numpy(gold["x"]), torch.from_numpy(gold["gout"])
+    out = m(x.to(dev))
+    out.backward(gout.to(dev))
+    e = rel_l2(out.detach().cpu(), torch.from_numpy(gold["train_logits"]))
+    print("mini train logits, fp16x3 forward, rel-L2 vs reference: %.2e" % e)
+    assert e < 1e-3
+    _, fl_grads = _oracle_run(blocks, state, x, gout, "fp16")
+    for name, p in m.named_parameters():
+        ref = torch.from_numpy(gold["grad/" + name])
+        ge, gf = rel_l2(p.grad.cpu(), ref), rel_l2(fl_grads[name], ref)
+        print("  grad %-28s rel-L2 %.2e (fp16-storage floor %.2e)" % (name, ge, gf))
+        assert ge < 1.5 * gf + 2e-3, name
+    sd = m.state_dict()
+    for k in sd:
+        if "running_" in k:
+            assert torch.allclose(sd[k].cpu(), torch.from_numpy(gold["after/" + k]), rtol=1e-4, atol=1e-5), k
+    m.eval()
+    with torch.no_grad():
+        e2 = rel_l2(m(x.to(dev)).cpu(), O.forward(blocks, {k: v.cpu() for k, v in m.state_dict().items()}, x, training=False))
+    print("mini eval logits after the step, fp16x3: %.2e" % e2)
+    assert e2 < 1e-4
 
 
 def _oracle_run(blocks, state, x, gout, storage, masks=None):
@@ -265,9 +298,19 @@ def test_yolov2_eval_logits_vs_golden(dev, tmp_path):
         out = m2(x.to(dev))
     ref = torch.from_numpy(np.load(os.path.join(HERE, "golden", "yolo_logits_b1.npz"))["logits"])
     e = rel_l2(out.cpu(), ref)
-    print("yolov2-voc eval logits (23 layers, fp16 storage) rel-L2 vs reference: %.2e" % e)
+    print("yolov2-voc eval logits (23 layers, default eval precision %r) rel-L2 vs reference: %.2e" % (m2.precision, e))
     assert out.shape == (1, 125, 13, 13)
-    assert e < 5e-3
+    assert e < 1e-3
+    # the other precision modes on the same input: split operands everywhere, and the plain-fp16 throughput mode
+    # against ITS floor (2.9e-4 per block in quadrature over 23 blocks, tools/error_budget.py)
+    errs = {}
+    for prec in ("fp16x3", "fp16"):
+        m2.precision = prec
+        with torch.no_grad():
+            errs[prec] = rel_l2(m2(x.to(dev)).cpu(), ref)
+    print("  fp16x3: %.2e   fp16 (throughput mode): %.2e" % (errs["fp16x3"], errs["fp16"]))
+    assert errs["fp16x3"] < 5e-5
+    assert errs["fp16"] < 2.5e-3
 
 
 def test_yolov2_eval_logits_b64_vs_oracle(dev):
@@ -286,7 +329,7 @@ def test_yolov2_eval_logits_b64_vs_oracle(dev):
     worst = max(rel_l2(out[i], ref[i]) for i in range(64))
     print("yolov2-voc eval logits at B=64: rel-L2 %.2e overall, %.2e worst image" % (e, worst))
     assert out.shape == (64, 125, 13, 13)
-    assert e < 5e-3 and worst < 1e-2
+    assert e < 1e-3 and worst < 1e-3
 
 
 @pytest.mark.parametrize("B", [3, 37, 96])
