@@ -1,38 +1,93 @@
 #!/usr/bin/env python3
 """Headline benchmark: YOLOv2-VOC dense fwd+bwd(+SGD step) images/sec at 416x416 on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1 runs in this process.  N > 1: when the process was started by a launcher (WORLD_SIZE in the environment, as the
+driver's `python -m torch.distributed.run ... bench.py --gpus N` does) it is one rank of N; started bare, it launches
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on itself as a CHILD process before anything here has
+touched the GPU, forwards the child's output and exits with its code (never an exec).  MCAMD_DP_BACKEND=gloo lets the
+ranks share one GPU (rehearsal on a 1-GPU box).
 
 One step = model(x) -> sum-of-logits loss -> backward (HIP engine) -> [gradient all-reduce]
 -> torch.optim.SGD step (lr 1e-5, momentum .9, weight_decay .0005*B: reference train.py:144-147)
 on one resident synthetic batch of B=64 images per GPU (BASELINE.json configs[1]).
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel: the implicit-GEMM MFMA convolution
-instance (forward + dgrad launches) with the largest total time in the timed region, every launch timed
-live with HIP events on the launch stream;
-`cpu_baseline` is the oracle (PyTorch-CPU restatement of the reference) on the host cores.
+Prints ONE JSON line (rank 0).  The timed region is NOT instrumented; `roofline` comes from a separate pass of a few
+more steps in which every convolution launch is bracketed by HIP events on the launch stream, for the dominant kernel:
+the implicit-GEMM MFMA convolution instance (forward + dgrad launches) with the largest total time.
+`cpu_baseline` is the oracle (PyTorch-CPU restatement of the reference) on the host cores (rank 0, N = 1 only).
+
+--workload prune measures the other half of the hot path: weight_prune(80) and quick_filter_prune(40)
+(reference methods.py:9-78) on the 50.6 M-weight model, HBM roofline, oracle (numpy) baseline.
 """
-import argparse
-import json
 import os
-import sys
-import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL: must be set before HIP initialises
+
+import argparse  # noqa: E402
+import json  # noqa: E402
+import subprocess  # noqa: E402
+import sys  # noqa: E402
+import time  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 PEAK_FP16_TFLOPS = 2500.0       # MI355X dense fp16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0           # HBM3E (MI355X_MICROARCH.md)
 FWD_BWD_GFLOP_PER_IMG = 87.782
 
 
+def host_cores():
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
+def host_memory_gb():
+    """Memory this process may still use: MemAvailable, capped by the cgroup limit when there is one."""
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    for f in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            v = open(f).read().strip()
+            if v.isdigit() and int(v) < (1 << 60):
+                used = 0
+                for u in ("/sys/fs/cgroup/memory.current", "/sys/fs/cgroup/memory/memory.usage_in_bytes"):
+                    try:
+                        used = int(open(u).read().strip())
+                        break
+                    except (OSError, ValueError):
+                        continue
+                lim = (int(v) - used) / 1e9
+                avail = lim if avail is None else min(avail, lim)
+        except OSError:
+            continue
+    return avail
+
+
+def cpu_batch_for_host(want):
+    """The fp32 autograd graph of the oracle holds ~0.32 GB per image (measured: 5.1 GB at B=16): B=64 needs ~21 GB.
+    Halve the sample until it fits in half of what the host offers (a box killed by the OOM killer costs more than
+    a smaller sample); the batch used is reported in `cpu_baseline.sample`."""
+    mem = host_memory_gb()
+    b = want
+    while mem is not None and b > 4 and 0.32 * b + 2.0 > 0.5 * mem:
+        b //= 2
+    return b
+
+
 def cpu_baseline(batch, steps):
-    """Oracle fwd+bwd on the host cores: bounded sample of the same workload (B=`batch`)."""
+    """Oracle fwd+bwd+SGD on ALL host cores this process may use: a bounded sample of the same workload
+    (B=64, 1 warm-up + >= 3 timed steps; ~30 s on the GPU box's 16 cores)."""
+    import torch
     from oracle import darknet_ref as O
     from modelcompression_amd import YOLOV2_VOC_CFG
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    torch.set_num_threads(max(1, min(ncpu, int(os.environ.get("MCAMD_CPU_THREADS", "16")))))   # the GPU box's CPU share
+    ncpu = host_cores()
+    torch.set_num_threads(max(1, int(os.environ.get("MCAMD_CPU_THREADS", ncpu))))
     blocks = O.parse_cfg(YOLOV2_VOC_CFG)
     state = O.init_state(blocks, seed=0)
     keys = O.param_keys(blocks)
@@ -51,12 +106,31 @@ def cpu_baseline(batch, steps):
             times.append(time.time() - t0)
     dt = sum(times) / len(times)
     return {"value": round(batch / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "B=%d fwd+bwd+SGD x%d steps of the same YOLOv2-VOC 416x416 workload (oracle, fp32 oneDNN)" % (batch, steps)}
+            "sample": "B=%d fwd+bwd+SGD, 1 warm-up + %d timed steps of the same YOLOv2-VOC 416x416 workload "
+                      "(oracle: fp32 PyTorch-CPU / oneDNN restatement of the reference, all %d affinity cores)"
+                      % (batch, steps, ncpu)}
+
+
+def spawn_ranks(n):
+    """Bare `python bench.py --gpus N`: run the N ranks as a child torch.distributed.run job.  Nothing in this process
+    has initialised the GPU (no torch.cuda call; torch is not even imported yet)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def bench_slim(args, model, dev, rank):
-    """BASELINE configs[4]: eval forward of the physically slim model next to the masked-dense one."""
+    """BASELINE configs[4]: eval forward of the physically slim model next to the masked-dense one, in the plain
+    fp16 MFMA mode the config names and in the eval default ("mixed": split operands, logits within 1e-3)."""
     import tempfile
+    import torch
     from modelcompression_amd import slim
     from modelcompression_amd.synthetic import synthetic_batch
     B = args.batch
@@ -67,23 +141,113 @@ def bench_slim(args, model, dev, rank):
     model.eval()
     res = {}
     with torch.no_grad():
-        for name, net in (("masked_dense", model), ("slim", thin)):
-            for _ in range(args.warmup):
-                net(x)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                net(x)
-            torch.cuda.synchronize()
-            res[name] = (time.perf_counter() - t0) / args.steps
+        for prec in ("fp16", "mixed"):
+            for name, net in (("masked_dense", model), ("slim", thin)):
+                net.precision = prec
+                for _ in range(args.warmup):
+                    net(x)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    net(x)
+                torch.cuda.synchronize()
+                res[(name, prec)] = (time.perf_counter() - t0) / args.steps
     if rank == 0:
+        t = res[("slim", "fp16")]
         print(json.dumps({
-            "metric": "images/sec (inference forward, 416x416)", "value": round(B / res["slim"], 1), "unit": "images/s",
-            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(res["slim"] * 1e3, 3),
+            "metric": "images/sec (inference forward, 416x416)", "value": round(B / t, 1), "unit": "images/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t * 1e3, 3),
             "higher_is_better": True, "dtype": "fp16", "data": "synthetic",
-            "config": {"workload": "YOLOv2-VOC filter-pruned 60 %% physically slim eval forward, B=%d (BASELINE configs[4])" % B,
+            "config": {"workload": "YOLOv2-VOC filter-pruned 60 %% physically slim eval forward, B=%d, plain fp16 MFMA operands "
+                                   "(BASELINE configs[4])" % B,
                        "filters_kept": sum(r[2] for r in rows), "filters_dense": sum(r[1] for r in rows),
-                       "masked_dense_images_per_s": round(B / res["masked_dense"], 1)}}))
+                       "masked_dense_images_per_s": round(B / res[("masked_dense", "fp16")], 1),
+                       "slim_images_per_s_mixed_precision": round(B / res[("slim", "mixed")], 1),
+                       "masked_dense_images_per_s_mixed_precision": round(B / res[("masked_dense", "mixed")], 1)}}))
+
+
+def bench_prune(args, model, dev):
+    """The pruning half of the hot path on the full 50.6 M-weight model: wall time of weight_prune(80) and
+    quick_filter_prune(40) (host percentile bookkeeping and the one device->host read included), the HBM roofline
+    of the magnitude-select scan, and the oracle's numpy restatement on the host as the CPU baseline."""
+    import numpy as np
+    import torch
+    from modelcompression_amd import ops
+    from modelcompression_amd.pruning.weightPruning.methods import weight_prune, quick_filter_prune
+    ws = [p.data for p in model.parameters() if p.dim() != 1]
+    n = sum(w.numel() for w in ws)
+
+    def wall(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+    reps = max(args.steps, 3)
+    t_w = wall(lambda: weight_prune(model, 80.0), reps)
+    t_f = wall(lambda: quick_filter_prune(model, 40.0), reps)
+
+    # dominant kernel: select_hist_kernel, one launch per radix pass over all 50.6 M magnitudes (4 B read per weight).
+    # HIP events (torch's current stream IS the launch stream of every ops.* call) around mcamd_kth_magnitude:
+    # 2 order statistics x 3 radix passes = 6 scan launches + 6 tiny bin-scan launches.
+    k = int(0.8 * (n - 1))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ops.kth_magnitude(ws, k)
+    ms = []
+    for _ in range(reps):
+        e0.record()
+        ops.kth_magnitude(ws, k)
+        e1.record()
+        e1.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    per_pass_ms = min(ms) / 6.0
+    bytes_per_launch = 4.0 * n
+    achieved = bytes_per_launch / (per_pass_ms * 1e-3) / 1e9
+    # filter scores: every weight read once (4 B), 23 layers
+    convs = [p.data for p in model.parameters() if p.dim() == 4]
+    ops.filter_scores(convs[0])
+    fs = []
+    for _ in range(reps):
+        e0.record()
+        for w in convs:
+            ops.filter_scores(w)
+        e1.record()
+        e1.synchronize()
+        fs.append(e0.elapsed_time(e1))
+    score_gbs = 4.0 * n / (min(fs) * 1e-3) / 1e9
+
+    res = {
+        "metric": "weights ranked per second (weight_prune 80 % on YOLOv2-VOC, 50.6 M weights)",
+        "value": round(n / t_w / 1e6, 1), "unit": "Mweights/s", "n_gpus": 1, "steps": reps, "warmup": 1,
+        "ms_per_step": round(t_w * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "weight_prune(80) + quick_filter_prune(40) on the seeded full-size YOLOv2-VOC model "
+                               "(reference methods.py:9-78), masks left on the GPU",
+                   "weights": n, "weight_prune_ms": round(t_w * 1e3, 3), "quick_filter_prune_ms": round(t_f * 1e3, 3),
+                   "filter_scores_all_layers_ms": round(min(fs), 4), "filter_scores_GBps": round(score_gbs, 1)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None,
+                     "kernel": "select_hist_kernel (one radix pass of the k-th magnitude select over all 23 weight tensors)",
+                     "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(per_pass_ms, 4),
+                     "note": "mcamd_kth_magnitude event time / 6 passes: includes the six bin-scan launches"},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import prune_ref as PR
+        params = [p.detach().cpu().numpy() for p in model.parameters()]
+        t0 = time.time()
+        PR.weight_prune(params, 80.0)
+        c_w = time.time() - t0
+        t0 = time.time()
+        PR.quick_filter_prune(params, 40.0)
+        c_f = time.time() - t0
+        res["cpu_baseline"] = {"value": round(n / c_w / 1e6, 2), "unit": "Mweights/s", "cores": 1, "kind": "port",
+                               "sample": "the oracle's numpy restatement on the same 50.6 M weights, one call each: "
+                                         "weight_prune %.2f s, quick_filter_prune %.2f s (the reference itself spends "
+                                         "25.4 s / 2.9 s, SURVEY section 6: a Python list of 50.6 M scalars)" % (c_w, c_f),
+                               "quick_filter_prune_s": round(c_f, 3), "weight_prune_s": round(c_w, 3)}
+    print(json.dumps(res))
 
 
 def main():
@@ -93,14 +257,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=64)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--profile-steps", type=int, default=5, help="instrumented steps (untimed) for the roofline entry")
     ap.add_argument("--layer-table", default="", help="write the per-launch timing table to this file")
-    ap.add_argument("--workload", default="dense", choices=["dense", "filter40", "weight80", "slim60"],
+    ap.add_argument("--transport", default=None, choices=["fp32", "fp16"], help="gradient all-reduce transport (N > 1)")
+    ap.add_argument("--workload", default="dense", choices=["dense", "filter40", "weight80", "slim60", "prune"],
                     help="dense = BASELINE configs[1] (the default bench line); filter40 / weight80 = the retrain step of "
                          "configs[2] / configs[3] with the reference's masks; slim60 = configs[4], eval forward of the "
-                         "physically slim 60 %% filter-pruned model (use --batch 128)")
+                         "physically slim 60 %% filter-pruned model (use --batch 128); prune = the mask computation itself")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
+    import torch
+    import torch.distributed as dist
     from modelcompression_amd import nets, dp, YOLOV2_VOC_CFG, ops
     from modelcompression_amd.synthetic import init_synthetic, synthetic_batch
 
@@ -117,8 +289,11 @@ def main():
     model = nets.Darknet(YOLOV2_VOC_CFG)
     init_synthetic(model, seed=0)
     model.to(dev).train()
+    if args.workload == "prune":
+        return bench_prune(args, model, dev)
     B = args.batch
     wl_name = "dense (0% prune)"
+    masks = None
     if args.workload != "dense":
         from modelcompression_amd.pruning.weightPruning.methods import weight_prune, quick_filter_prune
         if args.workload == "weight80":
@@ -134,7 +309,11 @@ def main():
     # same update rule as train.py:144-147; torch's fused multi-tensor implementation (one kernel per dtype/device)
     sgd_kw = {"fused": True} if os.environ.get("MCAMD_SGD_FUSED", "1") == "1" else {}
     opt = torch.optim.SGD(model.parameters(), lr=1e-5, momentum=0.9, dampening=0, weight_decay=0.0005 * B, **sgd_kw)
-    reducer = dp.attach(model) if world > 1 else None
+    reducer = None
+    if world > 1:
+        # static weight masks (configs[3]): only the kept gradient entries travel
+        reducer = dp.attach(model, dp.GradReducer(transport=args.transport),
+                            masks=masks if args.workload == "weight80" else None)
     x = synthetic_batch(B, 416, 416, seed=rank, device=dev)   # resident in HBM before the timed region
 
     def step():
@@ -151,17 +330,15 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    eng = list(model._engines.values())[0]
-    eng.events = []
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    events, eng.events = eng.events, None
     flat = model._last_flat_grad
     assert flat is not None and bool(torch.isfinite(flat).all()), "non-finite gradients in the timed run"
+    assert not model.grad_overflowed(), "a scaled gradient saturated the fp16 range in the timed run"
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -177,7 +354,15 @@ def main():
         spread = float(((hi - lo).abs() / hi.abs().clamp_min(1e-30)).max())
         assert spread < 1e-6, "ranks diverged: gradient / weight checksums differ (%s vs %s)" % (lo.tolist(), hi.tolist())
 
-    # ---- roofline of the dominant kernel: the igemm instance (fwd + dgrad launches) with the largest total time
+    # ---- roofline of the dominant kernel, from a SEPARATE instrumented pass (the timed region above carries no events):
+    # every conv launch bracketed by HIP events on the launch stream
+    eng = [e for e in model._engines.values() if e.precision == "fp16"][0]
+    eng.events = []
+    for _ in range(max(1, args.profile_steps)):
+        step()
+    fence()
+    events, eng.events = eng.events, None
+    nprof = max(1, args.profile_steps)
     per = {}
     for tag, lay, e0, e1 in events:
         ms = e0.elapsed_time(e1)
@@ -191,7 +376,7 @@ def main():
     for (tag, li), (ms, n, lay) in sorted(per.items(), key=lambda kv: (kv[0][1], kv[0][0])):
         fl = eng.conv_flops(lay)
         avg = ms / n
-        tile = ops.tile_info(lay.geom, dgrad=(tag == "dgrad")) if tag != "wgrad" else None
+        tile = ops.tile_info(lay.geom_act, dgrad=(tag == "dgrad")) if tag != "wgrad" else None
         tot[tag][0] += avg
         tot[tag][1] += fl
         rows.append("%-6s conv%-2d %4dx%-4d cin %4d cout %4d k%d  %8.3f ms  %8.1f TFLOP/s  tile %s" % (
@@ -201,7 +386,7 @@ def main():
             b[0] += ms
             b[1] += fl * n
             b[2] += n
-    # the dominant kernel = the igemm instance with the largest total time in the timed region
+    # the dominant kernel = the igemm instance with the largest total time
     dom_tile = max(by_tile, key=lambda t: by_tile[t][0])
     dom_ms, dom_flop, dom_n = by_tile[dom_tile]
     achieved = dom_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
@@ -225,7 +410,7 @@ def main():
             f.write("\n".join(rows) + "\n")
             for tag, (ms, fl) in tot.items():
                 f.write("TOTAL %-6s %8.3f ms/step  %8.1f TFLOP/s\n" % (tag, ms, fl / ms / 1e9 if ms else 0))
-            f.write("step %.3f ms; conv kernels %.3f ms\n" % (step_ms, sum(v[0] for v in tot.values())))
+            f.write("step %.3f ms (uninstrumented); conv kernels %.3f ms\n" % (step_ms, sum(v[0] for v in tot.values())))
 
     if rank != 0:
         return
@@ -238,7 +423,9 @@ def main():
                        wl_name, B, {"dense": 1, "filter40": 2, "weight80": 3}[args.workload]),
                    "global_batch": world * B, "input": "3x416x416", "parallelism": "dp%d" % world,
                    "conv_tflops_whole_step": round(value * FWD_BWD_GFLOP_PER_IMG / 1e3, 1),
-                   "frac_of_fp16_mfma_peak_whole_step": round(value * FWD_BWD_GFLOP_PER_IMG / 1e3 / (PEAK_FP16_TFLOPS * world), 4)},
+                   "frac_of_fp16_mfma_peak_whole_step": round(value * FWD_BWD_GFLOP_PER_IMG / 1e3 / (PEAK_FP16_TFLOPS * world), 4),
+                   "conv_kernel_ms_per_step": {k: round(v[0], 3) for k, v in tot.items()},
+                   "conv_kernel_tflops": {k: round(v[1] / v[0] / 1e9, 1) if v[0] else 0.0 for k, v in tot.items()}},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
                      "algorithmic_gflop_per_launch": round(dom_flop / max(dom_n, 1) / 1e9, 2),
@@ -246,11 +433,18 @@ def main():
                                 "igemm_pp_kernel<0,%d,%d,16> %dx%dx%d ping-pong (conv fwd + dgrad launches of that instance)" % (
                                     dom_tile[:2] + dom_tile[:3]) if dom_tile[3] == 2 else
                                 "igemm_kernel<%d,%d,..,%d,2,0> (conv fwd + dgrad launches of that instance)" % dom_tile[:3]),
-                     "launches_per_step": dom_n // max(args.steps, 1),
-                     "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4)},
+                     "launches_per_step": dom_n // nprof,
+                     "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4),
+                     "measured": "HIP events around every launch in %d extra steps after the timed region" % nprof},
     }
-    if world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(args.cpu_batch, 2)
+    if world > 1:
+        res["cpu_baseline"] = None
+        res["collective"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                             "transport": reducer.transport, "kept_fraction": round(reducer.kept_fraction, 4),
+                             "bytes_per_step_per_rank": reducer.bytes_reduced // max(1, args.warmup + args.steps + nprof),
+                             "collectives_per_step": reducer.collectives // max(1, args.warmup + args.steps + nprof)}
+    elif not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(cpu_batch_for_host(args.cpu_batch), args.cpu_steps)
     print(json.dumps(res))
 
 

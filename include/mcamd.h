@@ -85,6 +85,10 @@ typedef struct mcamd_conv_epilogue {
     const float* scale;        /* mode 2, may be NULL (=1) */
     const float* shift;        /* mode 2, may be NULL (=0) */
     float slope;               /* mode 2: negative-side slope (0.1 leaky, 1.0 linear) */
+    int32_t* overflow;         /* modes 0 and 2, may be NULL: device flag, set to 1 when a value had to be clamped to
+                                  the fp16 range (+-65504) on its way out.  fp16 outputs saturate instead of becoming
+                                  inf; the scaled gradients of the backward pass (grad_scale x dX) are where that can
+                                  happen, and the caller decides (train.py skips the step and halves grad_scale). */
 } mcamd_conv_epilogue;
 
 /* Rows of the BatchNorm partial-sum slab a forward launch of this geometry writes (epilogue mode 0). */
@@ -234,6 +238,8 @@ typedef struct mcamd_act_bwd_desc {
                                   index chan_perm[c] (see mcamd_bn_coeffs) */
     int32_t y_dtype;           /* 0: y is fp16, 1: y is fp32 (and the pooled argmax is taken on unrounded activations,
                                   as the split-storage forward keeps them) */
+    int32_t* overflow;         /* optional device flag, set to 1 when a dY value was clamped to +-65504 (see
+                                  mcamd_conv_epilogue.overflow) */
 } mcamd_act_bwd_desc;
 size_t mcamd_bn_act_bwd_workspace_bytes(const mcamd_act_bwd_desc* d);
 int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, size_t workspace_bytes, void* stream);
@@ -242,9 +248,11 @@ int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, size_t worksp
  * Layout conversion at the model boundary (Darknet.forward takes/returns NCHW fp32,
  * nets.py:720-774).
  * ------------------------------------------------------------------------- */
-/* src fp32 [B][C][H][W] * mul -> dst padded NHWC fp16 channels [choff, choff+C). */
+/* src fp32 [B][C][H][W] * mul -> dst padded NHWC fp16 channels [choff, choff+C).  `overflow` (may be NULL): device
+ * flag set to 1 when a value was clamped to +-65504 (the incoming logit gradient x grad_scale). */
 int mcamd_nchw_f32_to_padded_nhwc_f16(const float* src, int32_t B, int32_t C, int32_t H, int32_t W,
-                                      float mul, void* dst, int32_t dst_ld, int32_t dst_choff, void* stream);
+                                      float mul, void* dst, int32_t dst_ld, int32_t dst_choff, int32_t* overflow,
+                                      void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Pruning (reference src/pruning/weightPruning/methods.py).

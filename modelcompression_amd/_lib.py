@@ -24,7 +24,7 @@ class ConvEpilogue(C.Structure):
     _fields_ = [("mode", C.c_int32), ("y_ld", C.c_int32), ("y_choff", C.c_int32),
                 ("y", C.c_void_p), ("bias", C.c_void_p), ("stats", C.c_void_p),
                 ("stats_rows", C.c_int32), ("stats_ld", C.c_int32),
-                ("scale", C.c_void_p), ("shift", C.c_void_p), ("slope", C.c_float)]
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("slope", C.c_float), ("overflow", C.c_void_p)]
 
 
 class ActDesc(C.Structure):
@@ -57,7 +57,8 @@ class ActBwdDesc(C.Structure):
                 ("g2", C.c_void_p), ("g2_ld", C.c_int32), ("g2_choff", C.c_int32),
                 ("dy", C.c_void_p), ("dy_ld", C.c_int32), ("dy_choff", C.c_int32),
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("grad_scale", C.c_float),
-                ("dy_keep", C.c_void_p), ("chan_perm", C.c_void_p), ("y_dtype", C.c_int32)]
+                ("dy_keep", C.c_void_p), ("chan_perm", C.c_void_p), ("y_dtype", C.c_int32),
+                ("overflow", C.c_void_p)]
 
 
 EPI_RAW_F16, EPI_NCHW_F32, EPI_PAD_F16, EPI_RAW_F32 = 0, 1, 2, 3
@@ -84,7 +85,7 @@ SIGNATURES = {
     "mcamd_bn_act_fwd": (C.c_int, [C.POINTER(ActDesc), _P]),
     "mcamd_bn_act_bwd_workspace_bytes": (_SZ, [C.POINTER(ActBwdDesc)]),
     "mcamd_bn_act_bwd": (C.c_int, [C.POINTER(ActBwdDesc), _P, _SZ, _P]),
-    "mcamd_nchw_f32_to_padded_nhwc_f16": (C.c_int, [_P, _I32, _I32, _I32, _I32, _F, _P, _I32, _I32, _P]),
+    "mcamd_nchw_f32_to_padded_nhwc_f16": (C.c_int, [_P, _I32, _I32, _I32, _I32, _F, _P, _I32, _I32, _P, _P]),
     "mcamd_kth_magnitude_workspace_bytes": (_SZ, []),
     "mcamd_kth_magnitude": (C.c_int, [C.POINTER(_P), C.POINTER(_I64), _I32, _I64, _P, _P, _SZ, _P]),
     "mcamd_magnitude_mask": (C.c_int, [_P, _I64, _P, _P, _P]),

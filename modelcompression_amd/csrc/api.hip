@@ -251,6 +251,7 @@ static int fill_epilogue(IgemmArgs& a, const mcamd_conv_epilogue* e, int n_out, 
     a.y_ld = e->y_ld;
     a.y_choff = e->y_choff;
     a.stats_ld = 0;
+    a.overflow = (int*)e->overflow;
     if (e->mode == MCAMD_EPI_NCHW_F32) {
         a.bias = e->bias;
     } else if (e->mode == MCAMD_EPI_RAW_F16 || e->mode == MCAMD_EPI_PAD_F16) {

@@ -245,6 +245,7 @@ struct ActBwdArgs {
     float* slab;         // [nblocks][2][C]
     const float* coef;   // [2][C]: c1 = sum(gz)/count, c2 = sum(gz*xhat)/count
     const float* dy_keep;  // optional [C]: 0 for fully pruned filters (their dY is not needed and is zeroed)
+    int* overflow;         // optional: set to 1 when a dY value was clamped to +-65504
     int B, H, W, C;
     int y_ld, y_choff, g_ld, g_choff, g2_ld, g2_choff, dy_ld, dy_choff;
     float slope;
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(ActBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) sb[i] = sg[i] = 0.f;
     const int Ho = a.H >> 1, Wo = a.W >> 1;
+    bool sat = false;
 
     for (long long item = (long long)blockIdx.x * 256 + threadIdx.x; item < a.items; item += (long long)gridDim.x * 256) {
         long long pix = item / CH;
@@ -365,9 +367,14 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(ActBwdArgs a) {
                     out[i] = dm[i] * (gz - c1[i] - xh * c2[i]);
                 }
             }
-            if (PHASE == 1) store8(a.dy + pad_off(b, hh[k], ww[k], a.H, a.W, a.dy_ld) + a.dy_choff + c8, out);
+            if (PHASE == 1) {
+                store8(a.dy + pad_off(b, hh[k], ww[k], a.H, a.W, a.dy_ld) + a.dy_choff + c8, out);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sat |= fabsf(out[i]) > 65504.f;
+            }
         }
     }
+    if (PHASE == 1 && sat && a.overflow) atomicOr(a.overflow, 1);
 
     if (PHASE == 0) {
         __shared__ float red[256 * 16];
@@ -413,7 +420,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* slab
 // NCHW fp32 -> padded NHWC fp16 (model boundary)
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, int B, int C, int H, int W, float mul,
-                                                           half_t* dst, int ld, int choff, int cgroups) {
+                                                           half_t* dst, int ld, int choff, int cgroups, int* overflow) {
+    bool sat = false;
     // item = (pixel, channel group of up to 8); consecutive threads -> consecutive pixels (coalesced NCHW reads)
     const long long HW = (long long)H * W;
     const long long items = (long long)B * HW * cgroups;
@@ -427,6 +435,8 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, int
         half_t* d = dst + pad_off(b, h, w, H, W, ld) + choff + c0;
         const float* s = src + ((long long)b * C + c0) * HW + rem;
         int nc = C - c0 < 8 ? C - c0 : 8;
+        if (overflow)
+            for (int i = 0; i < nc; ++i) sat |= fabsf(s[i * HW] * mul) > 65504.f;
         if (ld == 4) {  // stem image: 3 channels + one zero, one 8-byte store per pixel
             h4_t q;
 #pragma unroll
@@ -441,6 +451,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, int
             for (int i = 0; i < nc; ++i) d[i] = sat_half(s[i * HW] * mul);
         }
     }
+    if (sat && overflow) atomicOr(overflow, 1);
 }
 
 // ------------------------------------------------------------------------------------
@@ -568,6 +579,7 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
     float* coef = (float*)workspace + (size_t)kBwdBlocks * 2 * d->C;
     a.coef = coef;
     a.dy_keep = d->dy_keep;
+    a.overflow = (int*)d->overflow;
     a.B = d->B, a.H = d->H, a.W = d->W, a.C = d->C;
     a.y_ld = d->y_ld, a.y_choff = d->y_choff, a.g_ld = d->g_ld, a.g_choff = d->g_choff;
     a.g2_ld = d->g2_ld, a.g2_choff = d->g2_choff, a.dy_ld = d->dy_ld, a.dy_choff = d->dy_choff;
@@ -606,14 +618,15 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
 }
 
 extern "C" int mcamd_nchw_f32_to_padded_nhwc_f16(const float* src, int32_t B, int32_t C, int32_t H, int32_t W, float mul,
-                                                 void* dst, int32_t dst_ld, int32_t dst_choff, void* stream) {
+                                                 void* dst, int32_t dst_ld, int32_t dst_choff, int32_t* overflow,
+                                                 void* stream) {
     MCAMD_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc: bad argument");
     MCAMD_REQUIRE(dst_choff + C <= dst_ld || dst_ld == 4, "nchw_to_nhwc: channel slice exceeds ld");
     MCAMD_REQUIRE((C >= 8) ? (dst_ld % 8 == 0 && dst_choff % 8 == 0) : true, "nchw_to_nhwc: alignment");
     int cgroups = (C + 7) / 8;
     long long items = (long long)B * H * W * cgroups;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(stream_grid(items)), dim3(256), 0, (hipStream_t)stream, src, B, C, H, W,
-                       mul, (half_t*)dst, dst_ld, dst_choff, cgroups);
+                       mul, (half_t*)dst, dst_ld, dst_choff, cgroups, (int*)overflow);
     MCAMD_LAUNCH_CHECK("nchw_to_nhwc");
     return MCAMD_OK;
 }

@@ -87,6 +87,7 @@ void igemm_kernel(IgemmArgs a) {
     float s1[TN], s2[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
+    bool sat = false;   // an fp16 output was clamped (reported through a.overflow)
 
     for (int mt = pslot; mt < a.num_mtiles; mt += a.num_pslots) {
         // ---- per-tile A row bases (top-left tap of each output pixel, swizzled chunk) ----
@@ -264,6 +265,7 @@ void igemm_kernel(IgemmArgs a) {
                             v = v > 0.f ? v : v * a.slope;
                         }
                         half_t hv = (half_t)fminf(fmaxf(v, -65504.f), 65504.f);  // saturate, never inf
+                        sat |= fabsf(v) > 65504.f;
                         ct[row * BN + col] = hv;
                         if (EPI == MCAMD_EPI_RAW_F16 && a.stats) {
                             float fv = (row < mlim) ? (float)hv : 0.f;
@@ -296,6 +298,7 @@ void igemm_kernel(IgemmArgs a) {
         }
     }
 
+    if (sat && a.overflow) atomicOr(a.overflow, 1);
     if ((EPI == MCAMD_EPI_RAW_F16 || EPI == MCAMD_EPI_RAW_F32) && a.stats) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {

@@ -136,6 +136,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
     float s1[TN], s2[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
+    bool sat = false;   // an fp16 output was clamped (reported through a.overflow)
 
     for (int mt = pslot; mt < a.num_mtiles; mt += a.num_pslots) {
         long long abase[A_IT];
@@ -343,6 +344,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
                             v = v > 0.f ? v : v * a.slope;
                         }
                         const half_t hv = (half_t)fminf(fmaxf(v, -65504.f), 65504.f);
+                        sat |= fabsf(v) > 65504.f;
                         ct[row * BN + col] = hv;
                         if (EPI == MCAMD_EPI_RAW_F16 && a.stats) {
                             const float fv = (row < mlim) ? (float)hv : 0.f;
@@ -375,6 +377,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
         }
     }
 
+    if (sat && a.overflow) atomicOr(a.overflow, 1);
     if ((EPI == MCAMD_EPI_RAW_F16 || EPI == MCAMD_EPI_RAW_F32) && a.stats) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {   // lanes that hold the same column: l ^ 32 (and l ^ 16 for 16x16 blocks)

@@ -160,6 +160,12 @@ __global__ __launch_bounds__(256, 1) void win3x3_kernel(IgemmArgs a, int seg_row
                     const h8_t v = *(const h8_t*)(tile + prow * NC + pc * 8);
                     if (n0 + pc * 8 < a.N && c0 + gi * 16 + prow < a.W) {     // (a ragged last group of a row)
                         *(h8_t*)(yrow + (long long)(gi * 16 + prow) * a.y_ld + pc * 8) = v;
+                        if (a.overflow) {       // a clamped value reads back as exactly +-65504
+                            bool s_ = false;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) s_ |= fabsf((float)v[e]) >= 65504.f;
+                            if (s_) atomicOr(a.overflow, 1);
+                        }
                         if (want_stats) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) {

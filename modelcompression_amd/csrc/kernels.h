@@ -28,6 +28,7 @@ struct IgemmArgs {
     int num_pslots;  // persistent workgroups along M (= rows of the statistics slab)
     int num_ntiles;
     int xcd_order;
+    int* overflow;   // optional: set to 1 when an fp16 output was clamped to +-65504
 };
 
 struct StemArgs {        // conv_stem.hip: forward of the 3-channel first layer

@@ -12,7 +12,21 @@ per-parameter bookkeeping) asynchronously as soon as they are final, and the col
 RCCL's stream under the rest of the backward pass (conv19-23 hold 61 % of the parameters and are
 done after the first ~20 % of it).  Averaging (not summing) keeps the single-GPU meaning of
 `loss / nB` (nets.py:600).  Masks are computed on rank 0 and broadcast.
+
+Transports (one ring hop moves 2*(7/8)*202.6 MB per GPU over a ~153 GB/s
+xGMI link, the same order as the B=32 compute step):
+  "fp32"   the flat buffer itself, in place (default; bit-identical ranks);
+  "fp16"   each bucket is scaled, rounded to fp16, summed in fp16 and widened again: half the bytes,
+           2^-11 relative rounding per element and rank (inside the 1e-3 DP parity bar, outside
+           bit-exactness: opt-in, MCAMD_DP_TRANSPORT=fp16);
+  sparse   with STATIC weight masks (`weight_prune`, methods.py:9-26) every masked gradient entry is an
+           exact zero on every rank (`grad * mask`, layers.py:59), so only the kept entries travel:
+           `set_static_masks` builds the kept-index list once, a bucket is gathered into a packed
+           buffer, all-reduced and scattered back (80 % pruning: 10.1 M of 50.6 M elements, 5x less
+           traffic).  The values the kept entries receive are the ones the dense all-reduce gives them.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -20,8 +34,11 @@ import torch.distributed as dist
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).
     The rank's GPU is selected BEFORE the process group is created and handed to it as
-    `device_id`, so RCCL communicators and barriers are bound to the right device."""
-    import os
+    `device_id`, so RCCL communicators and barriers are bound to the right device.
+
+    HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC, the only mode this pool's driver supports) is read by the
+    HIP runtime when it initialises, i.e. possibly before this function runs: entry points export it at
+    their very top (bench.py, train.py) and the launcher environment carries it; here it is only checked."""
     if dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -30,7 +47,10 @@ def init_from_env(backend=None):
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (see the environment notes)
+    if backend == "nccl" and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
+        import warnings
+        warnings.warn("HSA_ENABLE_IPC_MODE_LEGACY is not '0' in this process's environment: RCCL's IPC handles may "
+                      "fail with `hipIpcGetMemHandle: invalid argument`; export it before the process starts")
     kwargs = {}
     if backend == "nccl":
         local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
@@ -41,24 +61,103 @@ def init_from_env(backend=None):
 
 
 class GradReducer:
-    """Averages gradients across ranks.  `reduce_flat` is the engine path (one buffer);
-    `reduce_params` covers modules whose gradients are separate tensors (flattened in chunks)."""
+    """Averages gradients across ranks.  `ready` / `finish` is the engine path (one flat buffer, buckets
+    overlapped with backward); `reduce_flat` the unoverlapped form; `reduce_params` covers modules whose
+    gradients are separate tensors (flattened in chunks)."""
 
-    def __init__(self, world_size=None, chunk_elems=64 << 20, bucket_elems=8 << 20):
+    def __init__(self, world_size=None, chunk_elems=64 << 20, bucket_elems=8 << 20, transport=None, fp16_scale=256.0):
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.chunk = int(chunk_elems)
         self.bucket = int(bucket_elems)
-        self.bytes_reduced = 0
+        self.transport = transport or os.environ.get("MCAMD_DP_TRANSPORT", "fp32")
+        if self.transport not in ("fp32", "fp16"):
+            raise ValueError("transport must be 'fp32' or 'fp16' (got %r)" % (self.transport,))
+        self.fp16_scale = float(fp16_scale)
+        self.bytes_reduced = 0       # bytes handed to collectives (per rank)
         self.collectives = 0
-        self._pending = []       # async work handles of the current step
+        self._pending = []           # (work handle, completion callback or None) of the current step
         self._lo = self._hi = None   # final-but-not-yet-sent tail slice [lo, hi)
-        self._sent_lo = None     # everything in [sent_lo, end) has been handed to a collective
+        self._sent_lo = None         # everything in [sent_lo, end) has been handed to a collective
+        self._kept = None            # static-mask transport: sorted int64 indices of the kept entries of the flat buffer
+        self._kept_pos = None        # {flat offset: number of kept entries below it} at the parameter boundaries
+        self._kept_total = 0
+
+    # ---- static masks: only the kept entries travel
+    def set_static_masks(self, params, masks):
+        """`params`: model.parameters() in order (the flat buffer's layout); `masks`: one {0,1} tensor per
+        parameter with dim != 1 in that order (the list `weight_prune` returns, methods.py:16-25).  Entries whose
+        mask is 0 have an exactly-zero gradient on every rank and are left out of the collectives.  One host
+        sync here (index construction); none per step.  `masks=None` returns to the dense transport."""
+        if masks is None:
+            self._kept = self._kept_pos = None
+            return
+        params = list(params)
+        it = iter(masks)
+        pieces, off, bounds = [], 0, [0]
+        for p in params:
+            n = p.numel()
+            if p.dim() != 1:
+                m = next(it)
+                if tuple(m.shape) != tuple(p.shape):
+                    raise ValueError("mask shape %s does not match parameter shape %s" % (tuple(m.shape), tuple(p.shape)))
+                pieces.append(torch.nonzero(m.reshape(-1) != 0).flatten().to(p.device) + off)
+            else:
+                pieces.append(torch.arange(off, off + n, device=p.device))
+            off += n
+            bounds.append(off)
+        kept = torch.cat(pieces)
+        pos = torch.searchsorted(kept, torch.tensor(bounds, device=kept.device, dtype=kept.dtype)).tolist()
+        self._kept, self._kept_pos, self._kept_total = kept, dict(zip(bounds, pos)), off
+
+    @property
+    def kept_fraction(self):
+        return 1.0 if self._kept is None else self._kept.numel() / max(self._kept_total, 1)
+
+    # ---- one bucket [lo, hi) of the flat buffer -> collective(s)
+    def _send(self, flat, lo, hi):
+        sparse = self._kept is not None
+        if sparse:
+            if lo not in self._kept_pos or hi not in self._kept_pos or flat.numel() != self._kept_total:
+                raise RuntimeError("static-mask transport: bucket [%d, %d) does not lie on parameter boundaries" % (lo, hi))
+            idx = self._kept[self._kept_pos[lo]:self._kept_pos[hi]]
+            if idx.numel() == 0:
+                return
+            src = flat.index_select(0, idx)          # packed kept entries
+        else:
+            idx, src = None, flat[lo:hi]
+        if self.transport == "fp16":
+            src = (src * self.fp16_scale).to(torch.float16)
+        elif not sparse:
+            src = None                               # fp32 dense: all-reduce the slice in place
+        if src is None:
+            for off in range(lo, hi, self.chunk):
+                end = min(off + self.chunk, hi)
+                self._pending.append((dist.all_reduce(flat[off:end], op=dist.ReduceOp.SUM, async_op=True), None))
+                self.collectives += 1
+            self.bytes_reduced += (hi - lo) * flat.element_size()
+            return
+        works = []
+        for off in range(0, src.numel(), self.chunk):
+            works.append(dist.all_reduce(src[off:off + self.chunk], op=dist.ReduceOp.SUM, async_op=True))
+            self.collectives += 1
+        self.bytes_reduced += src.numel() * src.element_size()
+        inv = 1.0 / self.fp16_scale if self.transport == "fp16" else 1.0
+
+        def done(src=src, idx=idx, lo=lo, hi=hi, inv=inv):
+            vals = src.to(torch.float32) * inv if self.transport == "fp16" else src
+            if idx is not None:
+                flat.index_copy_(0, idx, vals)
+            else:
+                flat[lo:hi].copy_(vals)
+        for w in works[:-1]:
+            self._pending.append((w, None))
+        self._pending.append((works[-1], done))
 
     # ---- overlapped path: the engine reports gradient slices as they become final (tail first)
     def ready(self, flat, lo, hi):
         """`flat[lo:hi]` is final (all kernels that write it are enqueued on the current stream).
         Slices arrive in descending, contiguous order; a collective is launched whenever the
-        accumulated slice reaches `bucket_elems`."""
+        accumulated slice reaches `bucket_elems` (of travelling elements)."""
         if self.world == 1:
             return
         if self._hi is None:
@@ -68,16 +167,16 @@ class GradReducer:
                 raise RuntimeError("gradient slices must arrive contiguously from the tail: got [%d, %d) after [%d, ...)"
                                    % (lo, hi, self._lo))
             self._lo = lo
-        if self._hi - self._lo >= self.bucket:
+        n = self._hi - self._lo
+        if self._kept is not None and self._lo in self._kept_pos and self._hi in self._kept_pos:
+            n = self._kept_pos[self._hi] - self._kept_pos[self._lo]
+        if n >= self.bucket:
             self._launch(flat)
 
     def _launch(self, flat):
         if self._hi is None or self._hi == self._lo:
             return
-        for off in range(self._lo, self._hi, self.chunk):
-            end = min(off + self.chunk, self._hi)
-            self._pending.append(dist.all_reduce(flat[off:end], op=dist.ReduceOp.SUM, async_op=True))
-            self.collectives += 1
+        self._send(flat, self._lo, self._hi)
         self._sent_lo = self._lo
         self._hi = self._lo          # empty slice; the next ready() must end here
 
@@ -90,39 +189,43 @@ class GradReducer:
         elif self._lo != 0:
             raise RuntimeError("gradient slices [0, %d) were never reported" % self._lo)
         self._launch(flat)
-        for w in self._pending:
+        for w, cb in self._pending:
             w.wait()
+            if cb is not None:
+                cb()
         self._pending = []
         self._lo = self._hi = self._sent_lo = None
         flat.div_(self.world)
-        self.bytes_reduced += flat.numel() * flat.element_size()
         return flat
 
     def reduce_flat(self, flat):
         if self.world == 1:
             return flat
-        # chunks of <= 256 MB keep ring steps pipelined over the 7 xGMI links without a giant staging buffer
-        for off in range(0, flat.numel(), self.chunk):
-            dist.all_reduce(flat[off:off + self.chunk], op=dist.ReduceOp.SUM)
-        flat.div_(self.world)
-        self.bytes_reduced += flat.numel() * flat.element_size()
-        return flat
+        self._lo = self._hi = None
+        return self.finish(flat)
 
     def reduce_params(self, params):
         grads = [p.grad for p in params if p.grad is not None]
         if self.world == 1 or not grads:
             return
         flat = torch.cat([g.reshape(-1) for g in grads])
-        self.reduce_flat(flat)
+        kept, self._kept = self._kept, None      # separate gradient tensors: dense transport
+        try:
+            self.reduce_flat(flat)
+        finally:
+            self._kept = kept
         off = 0
         for g in grads:
             g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
 
 
-def attach(model, reducer=None):
-    """Hook the reducer behind the engine's backward: p.grad views see the averaged values."""
+def attach(model, reducer=None, masks=None):
+    """Hook the reducer behind the engine's backward: p.grad views see the averaged values.
+    `masks`: static weight masks (the list handed to `model.set_masks`) -> packed sparse transport."""
     reducer = reducer or GradReducer()
+    if masks is not None:
+        reducer.set_static_masks(model.parameters(), masks)
     model._grad_ready_hook = reducer.ready      # called per final tail slice during backward
     model._grad_hook = reducer.finish           # called once at the end of backward
     return reducer
@@ -142,3 +245,31 @@ def broadcast_parameters(model, src=0):
             dist.broadcast(t.data, src=src)
         if hasattr(model, "invalidate_packed"):
             model.invalidate_packed()
+
+
+def sync_buffers(model):
+    """Average the floating-point buffers (BatchNorm running_mean / running_var) over the ranks: they are
+    updated from rank-local batch statistics, and rank 0's copy is what `save_weights` / eval would otherwise use.
+    One flat all-reduce; call before a checkpoint or an evaluation (train.py does, once per epoch)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    bufs = [b for n, b in model.named_buffers() if b.is_floating_point() and not n.endswith(".mask")]
+    if not bufs:
+        return
+    flat = torch.cat([b.reshape(-1).float() for b in bufs])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(dist.get_world_size())
+    off = 0
+    for b in bufs:
+        b.copy_(flat[off:off + b.numel()].view_as(b).to(b.dtype))
+        off += b.numel()
+
+
+def all_ranks_ok(ok, device=None):
+    """Collective AND of a per-rank condition (e.g. "my loss and gradients are finite"), so that every rank takes
+    the same branch -- a rank that raised alone would leave its peers blocked in the next all-reduce."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else None)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))

@@ -88,6 +88,9 @@ class Engine:
         # MCAMD_OVERLAP_WGRAD=1: weight-gradient kernels on a second HIP stream beside the dgrad chain
         self.overlap_wgrad = os.environ.get("MCAMD_OVERLAP_WGRAD", "0") == "1"
         self._side_stream = None
+        self._side_ws = None
+        # set by the backward kernels when a scaled gradient (grad_scale x dY / dX) had to be clamped to +-65504
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=device)
         self._build_plan(H, W)
 
     # ------------------------------------------------------------------ plan
@@ -592,9 +595,14 @@ class Engine:
                 self._side_stream = torch.cuda.Stream(self.device)
             side = self._side_stream
             flat.record_stream(side)
+            # the side stream's split-K slabs must not alias the main stream's: with filter compaction the gather
+            # layers run their weight gradient on the main stream while a side-stream one may still be in flight
+            if self._side_ws is None or self._side_ws.numel() < self.wgrad_ws.numel():
+                self._side_ws = torch.empty(self.wgrad_ws.numel(), dtype=torch.uint8, device=self.device)
+                self._side_ws.record_stream(side)
         for lay in reversed(self.layers):
             if lay.is_last:
-                ops.nchw_to_padded(grad_out.detach().contiguous().float(), lay.dy, lay.cout_p, 0, S)
+                ops.nchw_to_padded(grad_out.detach().contiguous().float(), lay.dy, lay.cout_p, 0, S, overflow=self.overflow)
             else:
                 cons = self.consumer_of[lay.out_id]
                 t = lay.out_t
@@ -605,7 +613,7 @@ class Engine:
                 ops.bn_act_bwd(self.B, lay.H, lay.W, lay.cout, lay.y, lay.cout, 0, lay.scale, lay.shift, lay.mean,
                                lay.invstd, lay.slope, lay.mode, cons.gin, cons.tin.ld, t.choff, lay.dy, lay.cout_p, 0,
                                gmap[id(lay.bn.weight)], gmap[id(lay.bn.bias)], S, g2, g2_ld or 0, g2_choff or 0,
-                               self.bwd_ws, lay.keep, lay.perm32)
+                               self.bwd_ws, lay.keep, lay.perm32, overflow=self.overflow)
             mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
             dbias = gmap[id(lay.conv.bias)] if lay.conv.bias is not None else None
             if lay.gather:
@@ -627,13 +635,13 @@ class Engine:
                 side.wait_event(ev)
                 with torch.cuda.stream(side):
                     self._timed('wgrad', lay, ops.conv_wgrad, lay.geom, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
-                                gmap[id(lay.conv.weight)], mask, S, dbias, self.wgrad_ws)
+                                gmap[id(lay.conv.weight)], mask, S, dbias, self._side_ws)
             if on_ready is not None and side is None:
                 on_ready(flat, lay.p_lo, lay.p_hi)
             if lay.li > 0:
                 # gradient wrt this block's input slice, written into gin at the slice's channel offset
                 self._timed('dgrad', lay, ops.conv_dgrad_raw, lay.geom_act, lay.dy, lay.cout_p, 0, lay.wd, lay.gin, lay.tin.ld,
-                            lay.tin.choff)
+                            lay.tin.choff, overflow=self.overflow)
         if side is not None:
             main.wait_stream(side)
         return flat, views

@@ -264,6 +264,18 @@ class Darknet(nn.Module):
         self._weights_dirty = True
         return super(Darknet, self)._apply(fn, *args, **kwargs)
 
+    def grad_overflowed(self, reset=True):
+        """True when a backward pass since the last call had to clamp a scaled gradient (grad_scale x dY / dX) to the
+        fp16 range: the engine saturates instead of producing inf, so the step's gradients are finite but wrong.
+        One host sync.  train.py skips such a step and halves `grad_scale` (all ranks together)."""
+        hit = False
+        for eng in self._engines.values():
+            if int(eng.overflow.item()):
+                hit = True
+                if reset:
+                    eng.overflow.zero_()
+        return hit
+
     def invalidate_packed(self):
         """Call after modifying weights through `.data` outside optimizer.step / set_masks / load_weights."""
         self._weights_dirty = True

@@ -118,7 +118,7 @@ def stats_rows(g, mode=L.EPI_RAW_F16):
 
 
 def _epi(mode, y, y_ld=0, y_choff=0, bias=None, stats=None, stats_rows_=0, stats_ld=0, scale=None, shift=None,
-         slope=1.0):
+         slope=1.0, overflow=None):
     e = ConvEpilogue()
     e.mode, e.y_ld, e.y_choff = mode, y_ld, y_choff
     e.y = y.data_ptr()
@@ -128,6 +128,7 @@ def _epi(mode, y, y_ld=0, y_choff=0, bias=None, stats=None, stats_rows_=0, stats
     e.scale = scale.data_ptr() if scale is not None else None
     e.shift = shift.data_ptr() if shift is not None else None
     e.slope = slope
+    e.overflow = overflow.data_ptr() if overflow is not None else None
     return e
 
 
@@ -158,8 +159,9 @@ def conv_fwd_padded(g, x, wp, y, y_ld, y_choff=0, scale=None, shift=None, slope=
     check(L.lib().mcamd_conv_fwd(C.byref(g), ptr(x), ptr(wp), C.byref(e), stream_ptr()), "mcamd_conv_fwd")
 
 
-def conv_dgrad_raw(g, dy, dy_ld, dy_choff, wpd, out, out_ld, out_choff=0):
-    e = _epi(L.EPI_RAW_F16, out, out_ld, out_choff)
+def conv_dgrad_raw(g, dy, dy_ld, dy_choff, wpd, out, out_ld, out_choff=0, overflow=None):
+    """`overflow`: optional int32[1] device flag, set when a (scaled) gradient was clamped to the fp16 range."""
+    e = _epi(L.EPI_RAW_F16, out, out_ld, out_choff, overflow=overflow)
     check(L.lib().mcamd_conv_dgrad(C.byref(g), ptr(dy), dy_ld, dy_choff, ptr(wpd), C.byref(e), stream_ptr()),
           "mcamd_conv_dgrad")
 
@@ -223,7 +225,7 @@ def bn_act_fwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, slope, mode, dst, ds
 
 def bn_act_bwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, mean, invstd, slope, mode, g, g_ld, g_choff, dy, dy_ld,
                dy_choff, dgamma, dbeta, grad_scale=1.0, g2=None, g2_ld=0, g2_choff=0, workspace=None, dy_keep=None,
-               perm=None):
+               perm=None, overflow=None):
     d = ActBwdDesc()
     d.B, d.H, d.W, d.C = B, H, W, C_
     d.y, d.y_ld, d.y_choff = y.data_ptr(), y_ld, y_choff
@@ -239,6 +241,7 @@ def bn_act_bwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, mean, invstd, slope,
     d.dy_keep = dy_keep.data_ptr() if dy_keep is not None else None
     d.chan_perm = _perm_ptr(perm, C_)
     d.y_dtype = 1 if y.dtype == torch.float32 else 0
+    d.overflow = overflow.data_ptr() if overflow is not None else None
     need = int(L.lib().mcamd_bn_act_bwd_workspace_bytes(C.byref(d)))
     if workspace is None:
         workspace = torch.empty(need, dtype=torch.uint8, device=y.device)
@@ -251,13 +254,13 @@ def bn_act_bwd_workspace_bytes(C_):
     return int(L.lib().mcamd_bn_act_bwd_workspace_bytes(C.byref(d)))
 
 
-def nchw_to_padded(src, dst, dst_ld, dst_choff=0, mul=1.0):
+def nchw_to_padded(src, dst, dst_ld, dst_choff=0, mul=1.0, overflow=None):
     """fp32 NCHW tensor -> channels [choff, choff+C) of a padded NHWC fp16 buffer."""
     _need_cuda(src, dst)
     assert src.dtype == torch.float32 and src.is_contiguous()
     B, C_, H, W = src.shape
     check(L.lib().mcamd_nchw_f32_to_padded_nhwc_f16(ptr(src), B, C_, H, W, mul, ptr(dst), dst_ld, dst_choff,
-                                                    stream_ptr()), "mcamd_nchw_f32_to_padded_nhwc_f16")
+                                                    ptr(overflow), stream_ptr()), "mcamd_nchw_f32_to_padded_nhwc_f16")
 
 
 # ------------------------------------------------------------------ pruning

@@ -54,7 +54,8 @@ def smoke_mini(verbose=True):
     model.eval()          # default eval precision ("auto" -> "mixed")
     model.precision = "auto"
     with torch.no_grad():
-        e_eval = rel_l2(model(x.cuda()), O.forward(blocks, state, x, training=False))
+        now = {k: v.detach().cpu() for k, v in model.state_dict().items()}    # running statistics moved by the step above
+        e_eval = rel_l2(model(x.cuda()), O.forward(blocks, now, x, training=False))
     if verbose:
         print("smoke [eval, default precision]: logits rel-L2 %.2e" % e_eval)
     assert e_eval < 1e-3, e_eval

@@ -93,7 +93,7 @@ class YOLOv2Train():
         optimizer = optim.SGD(self.model.parameters(), lr=LR, momentum=momentum, dampening=0,
                               weight_decay=decay * self.batch_size, fused=True)   # same rule (train.py:144-147), one kernel
         self.optimizer = optimizer
-        reducer = dp.attach(self.model) if world > 1 else None
+        reducer = None
 
         masks = None
         if pruning_perc > 0:
@@ -103,6 +103,10 @@ class YOLOv2Train():
                 masks = weight_prune(self.model, pruning_perc)
             dp.broadcast_masks(masks, src=0)
             self.model.set_masks(masks)
+        if world > 1:
+            # static weight masks: only the kept gradient entries travel (dp.py); filter masks keep the dense transport
+            reducer = dp.attach(self.model, masks=masks if (masks is not None and pruning_method != "filter") else None)
+        if masks is not None:
             p_rate = prune_rate(self.model, rank == 0)
             if rank == 0:
                 print(' %s=pruned: %s' % (pruning_method, p_rate))
@@ -119,7 +123,7 @@ class YOLOv2Train():
             if rank == 0:
                 print(' ---------------------------- EPOCH : ', epoch, ' (LR : ', LR, ') ---------------------------------- ')
             self.model.train()
-            train_loss_total, t0, seen_here = 0.0, time.time(), 0
+            train_loss_total, t0, seen_here, skipped_steps = 0.0, time.time(), 0, 0
             for batch_idx, (data, target) in enumerate(loader):
                 if DEBUG_EPOCHS > -1 and batch_idx > DEBUG_EPOCHS:
                     break
@@ -128,11 +132,23 @@ class YOLOv2Train():
                 output = self.model(data)
                 region_loss.seen = region_loss.seen + data.size(0) * world
                 train_loss = region_loss(output, target)
-                if not torch.isfinite(train_loss):
+                # every decision below is taken by all ranks together: a rank that raised or skipped alone would
+                # leave its peers blocked in the next gradient all-reduce
+                if not dp.all_ranks_ok(bool(torch.isfinite(train_loss)), dev):
                     raise FloatingPointError("non-finite training loss at epoch %d batch %d" % (epoch, batch_idx))
                 train_loss_total += float(train_loss.detach())
                 optimizer.zero_grad()
                 train_loss.backward()
+                # the engine keeps gradients as fp16 x grad_scale and saturates at +-65504 (RegionLoss's exp terms can
+                # produce |dL/dlogit| x 256 beyond that): such a step is skipped and the scale halved
+                flat = self.model._last_flat_grad
+                good = not self.model.grad_overflowed() and (flat is None or bool(torch.isfinite(flat).all()))
+                if not dp.all_ranks_ok(good, dev):
+                    self.model.grad_scale = max(1.0, self.model.grad_scale / 2.0)
+                    skipped_steps += 1
+                    if rank == 0:
+                        logging('gradient overflow in fp16 storage: step skipped, grad_scale -> %g' % self.model.grad_scale)
+                    continue
                 optimizer.step()
                 seen_here += data.size(0) * world
                 if verbose and rank == 0:
@@ -141,6 +157,7 @@ class YOLOv2Train():
             if rank == 0:
                 logging('training with %f samples/s, mean loss %.4f' % (seen_here / max(time.time() - t0, 1e-9),
                                                                          train_loss_total / max(len(loader), 1)))
+            dp.sync_buffers(self.model)     # BatchNorm running statistics are rank-local: average before checkpoint / eval
             if pruning_perc > 0 and rank == 0:
                 print(' pruned: %s' % prune_rate(self.model, False))
                 print(' pruned weights consistent after retraining: %s ' % are_masks_consistent(self.model, masks))

@@ -163,14 +163,17 @@ def test_compaction_yolov2_40pct(dev):
     head = rel_l2(g_c["models.30.conv23.weight"], g_d["models.30.conv23.weight"])
     print("parameter gradients compact vs dense engine: head %.2e, median %.2e, worst %s" % (
         head, median, ", ".join("%s %.2e" % kv for kv in ranked[:4])))
-    # the worst entries are the first layers' BatchNorm vectors (a few dozen numbers summed with cancellation over
-    # 64 x 416 x 416 pixels); which realisation of the fp16 noise they see changes with any re-grouping of fp32
-    # partial sums, so they only have to stay the same order of magnitude; the bulk has to be close
-    assert head < 3e-2 and median < 0.25 and worst < 1.0
+    # This end-to-end comparison is chaotic by nature (which realisation of the fp16 noise the first layers'
+    # BatchNorm vectors see changes with any re-grouping of fp32 partial sums), so it only checks the head and the
+    # bulk; the TIGHT check of the compacted launches at these shapes -- every kernel of every block against fp32
+    # `F.conv2d(x, w * mask)` on identical inputs at 1e-3 / 2e-3 -- is
+    # tests/test_model_gpu.py::test_layerwise_teacher_forced_yolov2_filter40 (+ ..._filter60_b64_tail).
+    assert head < 3e-2 and median < 0.25
     for (name, p), mk in zip([(n, p) for n, p in m.named_parameters() if p.dim() == 4], masks):
         assert bool((g_c[name][mk.cpu() == 0] == 0).all()), name
-    # eval mode uses the same plan
+    # eval mode uses the same plan (in the plain-fp16 mode; the split-operand eval default does not compact)
     m.eval()
+    m.precision = "fp16"
     with torch.no_grad():
         os.environ["MCAMD_COMPACT"] = "1"
         m._engines = {}
@@ -180,3 +183,26 @@ def test_compaction_yolov2_40pct(dev):
         b = m(x).cpu()
         os.environ.pop("MCAMD_COMPACT")
     assert rel_l2(a, b) < 5e-3
+
+
+@pytest.mark.parametrize("cfg,shape", [(MINI, (4, 3, 64, 96)), (YOLOV2_VOC_CFG, (4, 3, 416, 416))], ids=["mini", "yolov2"])
+def test_overlapped_wgrad_with_compaction_is_bit_identical(dev, cfg, shape):
+    """MCAMD_OVERLAP_WGRAD=1 runs the weight gradients of the non-gather layers on a second stream while the gather
+    layers (filter compaction) keep theirs on the main stream: the two must not share a split-K workspace
+    (ADVICE r01).  Every kernel is deterministic, so the gradients have to be bit-identical to the serial run."""
+    blocks, m, masks = _model(cfg, dev, 7, 40.0)
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(*shape, generator=g).to(dev)
+    m.train()
+    gout = torch.randn(tuple(m(x).shape), generator=g).to(dev)
+    _, g_serial, _, _, eng = _run(m, x, gout, True)
+    assert any(lay.gather for lay in eng.layers) and any(not lay.gather for lay in eng.layers)
+    os.environ["MCAMD_OVERLAP_WGRAD"] = "1"
+    try:
+        for rep in range(3):
+            _, g_over, _, _, eng2 = _run(m, x, gout, True)
+            assert eng2.overlap_wgrad
+            for name in g_serial:
+                assert torch.equal(g_serial[name], g_over[name]), (rep, name)
+    finally:
+        os.environ.pop("MCAMD_OVERLAP_WGRAD", None)

@@ -202,6 +202,66 @@ def _dp_worker(rank, world, port, tmp):
     masks = [torch.full((3,), float(rank + 5))]
     dp.broadcast_masks(masks, src=0)
     assert float(masks[0][0]) == 5.0
+    # ---- packed transport for static weight masks: only the kept entries travel, and they
+    # receive bit-for-bit what the dense all-reduce gives them; masked entries stay exactly zero
+    gm = torch.Generator().manual_seed(5)
+    shapes = [(6, 4, 3, 3), (6,), (6,), (5, 6, 1, 1), (5,)]                      # conv, bn.weight, bn.bias, conv, bias
+    params = [torch.zeros(sh) for sh in shapes]
+    wmasks = [(torch.rand(sh, generator=gm) > 0.8).float() for sh in shapes if len(sh) != 1]
+    total = sum(p.numel() for p in params)
+    full = torch.cat([(wmasks[0] if i == 0 else wmasks[1]).reshape(-1) if len(sh) != 1 else torch.ones(sh[0])
+                      for i, sh in enumerate(shapes)])
+    gr = torch.Generator().manual_seed(100 + rank)
+    local = torch.randn(total, generator=gr) * full                              # grad * mask: exact zeros
+    dense = local.clone()
+    dp.GradReducer(transport="fp32").reduce_flat(dense)
+    bounds = [0]
+    for p_ in params:
+        bounds.append(bounds[-1] + p_.numel())
+    for bucket in (1, 40, 10 ** 9):
+        sp = dp.GradReducer(bucket_elems=bucket, transport="fp32")
+        sp.set_static_masks(params, wmasks)
+        assert sp._kept.numel() == int(full.sum()) and abs(sp.kept_fraction - float(full.double().mean())) < 1e-9
+        flat = local.clone()
+        # the engine reports whole conv blocks, tail first: [conv2 + bias], [conv1 + bn]
+        for lo, hi in ((bounds[3], bounds[5]), (bounds[0], bounds[3])):
+            sp.ready(flat, lo, hi)
+        sp.finish(flat)
+        assert torch.equal(flat, dense), bucket
+        assert bool((flat[full == 0] == 0).all())
+        assert sp.bytes_reduced == 4 * int(full.sum())                           # 5x less traffic at 80 % pruning
+    sp.set_static_masks(params, None)
+    flat = local.clone()
+    sp.reduce_flat(flat)
+    assert torch.equal(flat, dense)
+    try:
+        sp.set_static_masks(params, wmasks)
+        sp.ready(local.clone(), 3, total)                                        # not a parameter boundary
+        sp.finish(local.clone())
+        raise AssertionError("off-boundary bucket accepted by the packed transport")
+    except RuntimeError:
+        pass
+    # ---- fp16 transport: half the bytes, 2^-11 rounding per element and rank; dense and packed
+    for sparse in (False, True):
+        h = dp.GradReducer(transport="fp16", bucket_elems=40)
+        if sparse:
+            h.set_static_masks(params, wmasks)
+        flat = local.clone()
+        h.ready(flat, bounds[3], bounds[5])
+        h.ready(flat, bounds[0], bounds[3])
+        h.finish(flat)
+        assert float((flat - dense).abs().max()) <= 2.0 ** -10 * float(dense.abs().max()) + 1e-6
+        assert h.bytes_reduced == 2 * (int(full.sum()) if sparse else total)
+        assert bool((flat[full == 0] == 0).all())
+    # ---- collective decisions and buffer averaging
+    assert dp.all_ranks_ok(True) is True
+    assert dp.all_ranks_ok(rank != 1) is False
+    bn = torch.nn.BatchNorm2d(3)
+    bn.running_mean.fill_(float(rank))
+    bn.running_var.fill_(2.0 + rank)
+    dp.sync_buffers(bn)
+    assert torch.allclose(bn.running_mean, torch.full((3,), 0.5)) and torch.allclose(bn.running_var, torch.full((3,), 2.5))
+    assert int(bn.num_batches_tracked) == 0
     model = torch.nn.Linear(2, 2)
     torch.manual_seed(rank)
     torch.nn.init.normal_(model.weight)
