@@ -312,109 +312,74 @@ class Darknet(nn.Module):
         print_cfg(self.blocks)
 
     def create_network(self, blocks):
-        """nets.py:779-895: one module per non-[net] block; conv block =
-        Sequential(conv{id}: MaskedConv2d, bn{id}: BatchNorm2d, leaky{id}: LeakyReLU(0.1))."""
+        """nets.py:779-895: one module per non-[net] block, so that `models[i]` pairs with `blocks[i + 1]` and
+        `state_dict()` keys read `models.{i}.conv{id}.weight`.  Table-driven over the block types the engine runs
+        (convolutional, maxpool, reorg, route, region, cost); the reference's other branches (avgpool, softmax,
+        shortcut, connected: Darknet classifier / residual blocks that no YOLOv2 cfg of this project uses and the
+        engine has no kernels for) raise instead of building modules that could never execute."""
         models = nn.ModuleList()
-        prev_filters = 3
-        out_filters = []
-        conv_id = 0
+        widths = []                     # output channels of every module built so far
+        state = {"prev": 3, "conv_id": 0}
+
+        def conv(block):
+            state["conv_id"] += 1
+            cid, k, filters = state["conv_id"], int(block['size']), int(block['filters'])
+            pad = int((k - 1) / 2) if int(block['pad']) else 0          # 1x1 convs get pad 0 despite pad=1 (nets.py:796)
+            bn = int(block['batch_normalize'])
+            seq = nn.Sequential()
+            seq.add_module('conv%d' % cid, MaskedConv2d(state["prev"], filters, k, int(block['stride']), pad, bias=not bn))
+            if bn:
+                seq.add_module('bn%d' % cid, nn.BatchNorm2d(filters))
+            act = {'leaky': lambda: nn.LeakyReLU(0.1, inplace=True), 'relu': lambda: nn.ReLU(inplace=True)}.get(block['activation'])
+            if act is not None:
+                seq.add_module('%s%d' % (block['activation'], cid), act())
+            state["prev"] = filters
+            return seq, filters
+
+        def maxpool(block):
+            stride = int(block['stride'])
+            return (nn.MaxPool2d(int(block['size']), stride) if stride > 1 else MaxPoolStride1()), state["prev"]
+
+        def reorg(block):
+            stride = int(block['stride'])
+            state["prev"] = stride * stride * state["prev"]
+            return Reorg(stride), state["prev"]
+
+        def route(block):
+            ind = len(models)
+            src = [int(i) if int(i) > 0 else int(i) + ind for i in block['layers'].split(',')]
+            if len(src) == 2:
+                assert src[0] == ind - 1                                # nets.py:855
+            if len(src) in (1, 2):
+                state["prev"] = sum(widths[i] for i in src)
+            return EmptyModule(), state["prev"]
+
+        def region(block):
+            loss = RegionLoss()
+            loss.anchors = [float(i) for i in block['anchors'].split(',')]
+            loss.num_classes = int(block['classes'])
+            loss.num_anchors = int(block['num'])
+            loss.anchor_step = len(loss.anchors) / loss.num_anchors
+            for key in ('object_scale', 'noobject_scale', 'class_scale', 'coord_scale'):
+                setattr(loss, key, float(block[key]))
+            return loss, state["prev"]
+
+        def cost(block):
+            kinds = {'sse': nn.MSELoss, 'L1': nn.L1Loss, 'smooth': nn.SmoothL1Loss}
+            return kinds[block['_type']](reduction='mean'), 1
+
+        builders = {'convolutional': conv, 'maxpool': maxpool, 'reorg': reorg, 'route': route, 'region': region, 'cost': cost}
         for block in blocks:
             t = block['type']
             if t == 'net':
-                prev_filters = int(block['channels'])
+                state["prev"] = int(block['channels'])
                 continue
-            elif t == 'convolutional':
-                conv_id = conv_id + 1
-                batch_normalize = int(block['batch_normalize'])
-                filters = int(block['filters'])
-                kernel_size = int(block['size'])
-                stride = int(block['stride'])
-                is_pad = int(block['pad'])
-                pad = int((kernel_size - 1) / 2) if is_pad else 0
-                activation = block['activation']
-                model = nn.Sequential()
-                if batch_normalize:
-                    model.add_module('conv{0}'.format(conv_id),
-                                     MaskedConv2d(prev_filters, filters, kernel_size, stride, pad, bias=False))
-                    model.add_module('bn{0}'.format(conv_id), nn.BatchNorm2d(filters))
-                else:
-                    model.add_module('conv{0}'.format(conv_id),
-                                     MaskedConv2d(prev_filters, filters, kernel_size, stride, pad))
-                if activation == 'leaky':
-                    model.add_module('leaky{0}'.format(conv_id), nn.LeakyReLU(0.1, inplace=True))
-                elif activation == 'relu':
-                    model.add_module('relu{0}'.format(conv_id), nn.ReLU(inplace=True))
-                prev_filters = filters
-                out_filters.append(prev_filters)
-                models.append(model)
-            elif t == 'maxpool':
-                pool_size = int(block['size'])
-                stride = int(block['stride'])
-                model = nn.MaxPool2d(pool_size, stride) if stride > 1 else MaxPoolStride1()
-                out_filters.append(prev_filters)
-                models.append(model)
-            elif t == 'avgpool':
-                out_filters.append(prev_filters)
-                models.append(GlobalAvgPool2d())
-            elif t == 'softmax':
-                out_filters.append(prev_filters)
-                models.append(nn.Softmax())
-            elif t == 'cost':
-                if block['_type'] == 'sse':
-                    model = nn.MSELoss(reduction='mean')
-                elif block['_type'] == 'L1':
-                    model = nn.L1Loss(reduction='mean')
-                elif block['_type'] == 'smooth':
-                    model = nn.SmoothL1Loss(reduction='mean')
-                out_filters.append(1)
-                models.append(model)
-            elif t == 'reorg':
-                stride = int(block['stride'])
-                prev_filters = stride * stride * prev_filters
-                out_filters.append(prev_filters)
-                models.append(Reorg(stride))
-            elif t == 'route':
-                layers = block['layers'].split(',')
-                ind = len(models)
-                layers = [int(i) if int(i) > 0 else int(i) + ind for i in layers]
-                if len(layers) == 1:
-                    prev_filters = out_filters[layers[0]]
-                elif len(layers) == 2:
-                    assert (layers[0] == ind - 1)
-                    prev_filters = out_filters[layers[0]] + out_filters[layers[1]]
-                out_filters.append(prev_filters)
-                models.append(EmptyModule())
-            elif t == 'shortcut':
-                ind = len(models)
-                prev_filters = out_filters[ind - 1]
-                out_filters.append(prev_filters)
-                models.append(EmptyModule())
-            elif t == 'connected':
-                filters = int(block['output'])
-                if block['activation'] == 'linear':
-                    model = nn.Linear(prev_filters, filters)
-                elif block['activation'] == 'leaky':
-                    model = nn.Sequential(nn.Linear(prev_filters, filters), nn.LeakyReLU(0.1, inplace=True))
-                elif block['activation'] == 'relu':
-                    model = nn.Sequential(nn.Linear(prev_filters, filters), nn.ReLU(inplace=True))
-                prev_filters = filters
-                out_filters.append(prev_filters)
-                models.append(model)
-            elif t == 'region':
-                loss = RegionLoss()
-                anchors = block['anchors'].split(',')
-                loss.anchors = [float(i) for i in anchors]
-                loss.num_classes = int(block['classes'])
-                loss.num_anchors = int(block['num'])
-                loss.anchor_step = len(loss.anchors) / loss.num_anchors
-                loss.object_scale = float(block['object_scale'])
-                loss.noobject_scale = float(block['noobject_scale'])
-                loss.class_scale = float(block['class_scale'])
-                loss.coord_scale = float(block['coord_scale'])
-                out_filters.append(prev_filters)
-                models.append(loss)
-            else:
-                print('unknown type %s' % (block['type']))
+            if t not in builders:
+                raise NotImplementedError("cfg block [%s] is outside the YOLOv2 path this package executes "
+                                          "(supported: %s)" % (t, ', '.join(sorted(builders))))
+            module, width = builders[t](block)
+            models.append(module)
+            widths.append(width)
         return models
 
     def load_weights(self, weightfile):

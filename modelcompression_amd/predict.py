@@ -15,7 +15,7 @@ import torch
 
 from .data import VOCList, SyntheticDetection
 from .nets import getYOLOv2
-from .nets2_utils import get_region_boxes, nms, get_image_size
+from .nets2_utils import get_region_boxes, nms, detections, get_image_size  # noqa: F401
 
 
 class PASCALVOCEval():
@@ -63,19 +63,20 @@ class PASCALVOCEval():
                 output = self.MODEL(data.to(dev))
                 if self.LOGGER != '' and self.MODEL_LOSS is not None and bool((target != 0).any()):
                     val_loss_total += float(self.MODEL_LOSS(output, target.float().to(dev)))
-                batch_boxes = get_region_boxes(output, CONF_THRESH, self.MODEL.num_classes, self.MODEL.anchors,
-                                               self.MODEL.num_anchors, 0, 1)
+                # predict.py:148-173 (get_region_boxes(.., 0, 1) -> nms -> one line per class above the threshold) as one
+                # batched device computation; only the surviving detections come to the host
+                batch_dets = detections(output, CONF_THRESH, NMS_THRESH, self.MODEL.num_classes, self.MODEL.anchors,
+                                        self.MODEL.num_anchors)
                 for i in range(output.size(0)):
                     lineId += 1
                     fileId = os.path.basename(valid_files[lineId]).split('.')[0]
                     size = get_image_size(valid_files[lineId]) if have_list else None
                     width, height = size if size else (self.MODEL.width, self.MODEL.height)
-                    for box in nms(batch_boxes[i], NMS_THRESH):
+                    for box, classes in batch_dets[i]:
                         x1, y1 = (box[0] - box[2] / 2.0) * width, (box[1] - box[3] / 2.0) * height
                         x2, y2 = (box[0] + box[2] / 2.0) * width, (box[1] + box[3] / 2.0) * height
-                        for j in range(int((len(box) - 5) / 2)):
-                            prob = box[4] * box[5 + 2 * j]
-                            fps[int(box[6 + 2 * j])].write('%s %f %f %f %f %f\n' % (fileId, prob, x1, y1, x2, y2))
+                        for cls_id, prob in classes:
+                            fps[cls_id].write('%s %f %f %f %f %f\n' % (fileId, prob, x1, y1, x2, y2))
                             ndet += 1
         if self.LOGGER != '' and self.MODEL_LOSS is not None:
             self.LOGGER.save_value('Total Loss', 'Val Loss', self.LOGGER_EPOCH + 1, val_loss_total / max(len(loader), 1))

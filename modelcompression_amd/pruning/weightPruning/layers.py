@@ -1,4 +1,4 @@
-"""Mirror of the reference's src/pruning/weightPruning/layers.py (MaskedConv2d).
+"""Mirror of the reference's src/pruning/weightPruning/layers.py (MaskedConv2d, MaskedLinear).
 
 Same constructor, `set_mask` / `get_mask` / `forward`, `.name`, `.mask_flag` and registered
 `mask` buffer as layers.py:33-64.  `forward` on a CUDA tensor runs the hand-written HIP
@@ -90,3 +90,33 @@ class MaskedConv2d(nn.Conv2d):
     def forward(self, x):
         mask = self.mask.contiguous() if self.mask_flag else None
         return _masked_conv2d(x, self.weight, self.bias, mask, self.stride, self.padding, self.dilation, self.groups)
+
+
+class MaskedLinear(nn.Linear):
+    """layers.py:8-30.  y = x @ (weight * mask).T + bias is the 1x1 convolution of a 1x1 "image" with `in_features`
+    channels, so it runs on the same HIP kernels as MaskedConv2d (fp16 MFMA operands, fp32 accumulate; forward,
+    input gradient and masked weight gradient).  Not on the YOLOv2 path (no cfg of this project has a [connected]
+    block); provided because it is part of the package's surface."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super(MaskedLinear, self).__init__(in_features, out_features, bias)
+        self.mask_flag = False
+        self.name = 'MaskedLinear'
+
+    def set_mask(self, mask):
+        self.register_buffer('mask', mask.to(device=self.weight.device, dtype=self.weight.dtype))
+        mask_var = self.get_mask()
+        self.weight.data = self.weight.data * mask_var.data
+        self.mask_flag = True
+
+    def get_mask(self):
+        return self.mask
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise McamdError("MaskedLinear.forward needs a CUDA (MI355X) tensor: modelcompression_amd has no CPU path")
+        lead = x.shape[:-1]
+        x4 = x.reshape(-1, self.in_features, 1, 1)
+        w4 = self.weight.view(self.out_features, self.in_features, 1, 1)
+        mask = self.mask.contiguous().view_as(w4) if self.mask_flag else None
+        return _MaskedConvFn.apply(x4, w4, self.bias, mask).view(*lead, self.out_features)
