@@ -85,8 +85,10 @@ class Engine:
         self.serial = 0
         self._packed_sig = None
         self.events = None            # list of (tag, layer, start, end) HIP events while profiling
-        # MCAMD_OVERLAP_WGRAD=1: weight-gradient kernels on a second HIP stream beside the dgrad chain
-        self.overlap_wgrad = os.environ.get("MCAMD_OVERLAP_WGRAD", "0") == "1"
+        # weight-gradient kernels on a second HIP stream beside the dgrad / BN-backward chain (they fill each other's
+        # tails: +3.5 % images/s at B=64); MCAMD_OVERLAP_WGRAD=0 serialises everything on the launch stream (per-kernel
+        # timing passes do that, bench.py)
+        self.overlap_wgrad = os.environ.get("MCAMD_OVERLAP_WGRAD", "1") == "1"
         self._side_stream = None
         self._side_ws = None
         # set by the backward kernels when a scaled gradient (grad_scale x dY / dX) had to be clamped to +-65504
@@ -589,7 +591,7 @@ class Engine:
         views = [flat[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.params)]
         gmap = {id(p): v for p, v in zip(self.params, views)}
         side = main = None
-        if self.overlap_wgrad:
+        if self.overlap_wgrad and self.events is None:    # per-kernel timing: one stream, no overlapping launches
             main = torch.cuda.current_stream(self.device)
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream(self.device)
@@ -636,8 +638,18 @@ class Engine:
                 with torch.cuda.stream(side):
                     self._timed('wgrad', lay, ops.conv_wgrad, lay.geom, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
                                 gmap[id(lay.conv.weight)], mask, S, dbias, self._side_ws)
-            if on_ready is not None and side is None:
-                on_ready(flat, lay.p_lo, lay.p_hi)
+            if on_ready is not None:
+                if side is None:
+                    on_ready(flat, lay.p_lo, lay.p_hi)
+                else:
+                    # this block's slice is written from both streams (dgamma / dbeta and the gather layers' dW on the
+                    # main one, dW on the side one): the collective is enqueued from the side stream once it has also
+                    # seen everything the main stream has issued so far
+                    ev2 = torch.cuda.Event()
+                    ev2.record(main)
+                    side.wait_event(ev2)
+                    with torch.cuda.stream(side):
+                        on_ready(flat, lay.p_lo, lay.p_hi)
             if lay.li > 0:
                 # gradient wrt this block's input slice, written into gin at the slice's channel offset
                 self._timed('dgrad', lay, ops.conv_dgrad_raw, lay.geom_act, lay.dy, lay.cout_p, 0, lay.wd, lay.gin, lay.tin.ld,

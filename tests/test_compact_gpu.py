@@ -195,7 +195,9 @@ def test_overlapped_wgrad_with_compaction_is_bit_identical(dev, cfg, shape):
     x = torch.rand(*shape, generator=g).to(dev)
     m.train()
     gout = torch.randn(tuple(m(x).shape), generator=g).to(dev)
+    os.environ["MCAMD_OVERLAP_WGRAD"] = "0"
     _, g_serial, _, _, eng = _run(m, x, gout, True)
+    assert not eng.overlap_wgrad
     assert any(lay.gather for lay in eng.layers) and any(not lay.gather for lay in eng.layers)
     os.environ["MCAMD_OVERLAP_WGRAD"] = "1"
     try:
