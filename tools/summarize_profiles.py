@@ -2,7 +2,7 @@
 and the HBM traffic of the dominant kernel (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE)."""
 import collections, csv, glob, json, os, shutil, sys
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_final"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 os.makedirs("profiles", exist_ok=True)
 def one(pat):
     g = sorted(glob.glob(os.path.join(src, pat)), key=os.path.getmtime)   # newest run wins (gpurun merges runs)
@@ -54,3 +54,15 @@ if dom:
               open("profiles/dominant_kernel_traffic.json", "w"), indent=1)
     print(k, out[k])
 shutil.copy(os.path.join(src, "bench.json"), "profiles/%s_bench.json" % tag)
+
+# pruning workload: kernel stats + HBM bytes read per launch of the magnitude-select scan
+pst = one("prune_stats/*/*kernel_stats.csv")
+if pst:
+    shutil.copy(pst, "profiles/%s_prune_kernel_stats.csv" % tag)
+    pf = pmc("prune_fetch")
+    sel = {k: {"launches": int(v["launches"]), "avg_us": v["us"] / v["launches"],
+               "fetch_bytes_per_launch": v["FETCH_SIZE"] * 1024 * 2 / v["launches"]}
+           for k, v in pf.items() if "select_hist" in k or "filter_partial" in k or "magnitude_mask" in k or "filter_mask" in k}
+    json.dump(sel, open("profiles/%s_prune_pmc.json" % tag, "w"), indent=1)
+    if os.path.exists(os.path.join(src, "bench_prune.json")):
+        shutil.copy(os.path.join(src, "bench_prune.json"), "profiles/%s_bench_prune.json" % tag)
