@@ -245,6 +245,48 @@ size_t mcamd_bn_act_bwd_workspace_bytes(const mcamd_act_bwd_desc* d);
 int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * The first block as ONE unit: conv1 (3 -> 32 filters, 3x3) + BatchNorm2d + LeakyReLU
+ * + MaxPool2d(2,2) (reference src/nets.py:798-821 for the first [convolutional] +
+ * [maxpool] pair of yolov2-voc.cfg, F.conv2d at layers.py:60-64) without the block's
+ * full-resolution tensors: neither the raw conv output (709 MB at B=64) nor its
+ * gradient ever exists in HBM.  Batch statistics come from the 27x27 Gram matrix of
+ * the image windows (y = W v is linear in the 27-value window v), the forward pass
+ * recomputes nothing, the backward pass recomputes y from the image and reduces the
+ * weight gradient algebraically (csrc/conv_stem_block.hip).  Deterministic.
+ *   x      : stem input, padded NHWC4 fp16 (as mcamd_conv_geom.stem)
+ *   wp     : packed stem weights from mcamd_pack_weights (mask already applied)
+ *   dst    : pooled output, padded NHWC fp16 [B][H/2+2][W/2+2][dst_ld], pixel (0,0,0)
+ *   g      : gradient wrt dst, fp16 [B*(H/2)*(W/2)][g_ld], grad_scale x the true one
+ * Requires W % 32 == 0 and an even H.  `workspace` (mcamd_stem_block_workspace_bytes())
+ * carries S and W*C from a training-mode forward call to the backward call of the same
+ * step: the caller must not touch it in between.
+ * training != 0: batch statistics -> scale/shift/save_mean/save_invstd are WRITTEN and the
+ * running statistics updated; training == 0: scale/shift are READ (mcamd_bn_coeffs with
+ * stats == NULL provides them from the running statistics).
+ * ------------------------------------------------------------------------- */
+typedef struct mcamd_stem_block_desc {
+    int32_t B, H, W;                      /* conv resolution; cin = 3, cout = 32 */
+    const void* x;
+    const void* wp;
+    const float* gamma; const float* beta;
+    float* running_mean; float* running_var;   /* may be NULL */
+    float momentum, eps;
+    int32_t training;
+    float* scale; float* shift; float* save_mean; float* save_invstd;   /* fp32 [32] each */
+    float slope;                          /* 0.1 (leaky) or 1.0 (linear) */
+    void* dst; int32_t dst_ld, dst_choff;
+    /* backward only */
+    const void* g; int32_t g_ld, g_choff;
+    const float* mask;                    /* OIHW fp32 [32][3][3][3] or NULL */
+    float grad_scale;
+    float* dw;                            /* out: OIHW fp32, x mask, / grad_scale */
+    float* dgamma; float* dbeta;          /* out fp32 [32], / grad_scale (may be NULL) */
+} mcamd_stem_block_desc;
+size_t mcamd_stem_block_workspace_bytes(void);
+int mcamd_stem_block_fwd(const mcamd_stem_block_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+int mcamd_stem_block_bwd(const mcamd_stem_block_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Layout conversion at the model boundary (Darknet.forward takes/returns NCHW fp32,
  * nets.py:720-774).
  * ------------------------------------------------------------------------- */

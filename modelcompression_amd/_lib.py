@@ -61,6 +61,19 @@ class ActBwdDesc(C.Structure):
                 ("overflow", C.c_void_p)]
 
 
+class StemBlockDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("x", C.c_void_p), ("wp", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("momentum", C.c_float), ("eps", C.c_float), ("training", C.c_int32),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
+                ("slope", C.c_float),
+                ("dst", C.c_void_p), ("dst_ld", C.c_int32), ("dst_choff", C.c_int32),
+                ("g", C.c_void_p), ("g_ld", C.c_int32), ("g_choff", C.c_int32),
+                ("mask", C.c_void_p), ("grad_scale", C.c_float),
+                ("dw", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
+
+
 EPI_RAW_F16, EPI_NCHW_F32, EPI_PAD_F16, EPI_RAW_F32 = 0, 1, 2, 3
 DST_PLAIN, DST_POOL, DST_REORG = 0, 1, 2
 
@@ -85,6 +98,9 @@ SIGNATURES = {
     "mcamd_bn_act_fwd": (C.c_int, [C.POINTER(ActDesc), _P]),
     "mcamd_bn_act_bwd_workspace_bytes": (_SZ, [C.POINTER(ActBwdDesc)]),
     "mcamd_bn_act_bwd": (C.c_int, [C.POINTER(ActBwdDesc), _P, _SZ, _P]),
+    "mcamd_stem_block_workspace_bytes": (_SZ, []),
+    "mcamd_stem_block_fwd": (C.c_int, [C.POINTER(StemBlockDesc), _P, _SZ, _P]),
+    "mcamd_stem_block_bwd": (C.c_int, [C.POINTER(StemBlockDesc), _P, _SZ, _P]),
     "mcamd_nchw_f32_to_padded_nhwc_f16": (C.c_int, [_P, _I32, _I32, _I32, _I32, _F, _P, _I32, _I32, _P, _P]),
     "mcamd_kth_magnitude_workspace_bytes": (_SZ, []),
     "mcamd_kth_magnitude": (C.c_int, [C.POINTER(_P), C.POINTER(_I64), _I32, _I64, _P, _P, _SZ, _P]),

@@ -1,0 +1,650 @@
+// The whole first block of Darknet-19 -- conv1 (3 -> 32, 3x3) + BatchNorm(train) + LeakyReLU + MaxPool(2,2) -- forward
+// and backward WITHOUT ever storing the block's full-resolution tensors.
+//
+// At B = 64 the raw output of conv1 is 709 MB of fp16 (64 x 416 x 416 x 32) for 0.4 % of the network's FLOPs; the
+// unfused path writes it, reads it for BatchNorm + pool, reads it twice more in the BatchNorm backward, writes the
+// equally large dY and reads that again for the weight gradient: ~4.5 GB of HBM traffic and 1.05 ms of a 10.8 ms step.
+// Both tensors are redundant: the layer has only K = 27 inputs per pixel, so everything the BatchNorm needs from y is
+// a function of the 27 x 27 Gram matrix of the image windows, and y itself can be recomputed from the 88 MB image
+// faster than it can be read back.
+//
+//   v_m      = im2col row of output pixel m (27 values; slot (ty, tx, c)),   y[m][n] = W[n] . v_m
+//   C        = sum_m v_m v_m^T,   S = sum_m v_m                  (stem_gram_kernel: image only, MFMA F^T F)
+//   mean_n   = W[n] . S / M,      E[y^2]_n = W[n]^T C W[n] / M   (stem_coeffs_kernel, double)
+//   forward  : image -> y (registers) -> scale/shift -> 2x2 max -> LeakyReLU -> pooled fp16 output   (one pass)
+//   backward : recompute y and the window argmax from the image, g_z = G * leaky'(z) at the argmax position,
+//              T[n][k] = sum_m g_z[m][n] v_m[k] (MFMA), dbeta_n = sum_m g_z[m][n]                     (one pass)
+//              dgamma_n = invstd_n (W[n] . T[n] - mean_n dbeta_n)
+//              dW[n][k] = gamma_n invstd_n (T[n][k] - dbeta_n/M S[k] - dgamma_n/M invstd_n ((W C)[n][k] - mean_n S[k]))
+//   (the last line is dW = sum_m dy[m][n] v_m[k] with the BatchNorm backward dy = gamma invstd (g_z - mean(g_z) -
+//   xhat mean(g_z xhat)) expanded: sum_m xhat[m][n] v_m[k] = invstd_n ((W C)[n][k] - mean_n S[k]).)
+//
+// HBM traffic per step: image 3 x 88 MB + pooled output 177 MB + its gradient 177 MB.  y is never rounded to fp16,
+// so the block is closer to the fp32 reference than the unfused path.
+//
+// Replaces, for the first block, F.conv2d (reference src/pruning/weightPruning/layers.py:60-64), nn.BatchNorm2d,
+// nn.LeakyReLU(0.1), nn.MaxPool2d(2, 2) (src/nets.py:798-821) and their autograd backward.
+#include "kernels.h"
+#include "tr_frag.h"
+#include <stdlib.h>
+#include <string.h>
+
+namespace {
+
+struct StemBlockArgs {
+    const half_t* x;        // padded NHWC4 image, pixel (0, 0, 0)
+    const half_t* w;        // packed stem weights [>= 32][96], k = ty*32 + tx*4 + c
+    const float* scale;     // [32]
+    const float* shift;     // [32]
+    half_t* out;            // pooled output, padded NHWC pixel (0, 0, 0)
+    const half_t* g;        // gradient wrt the pooled output [B*H2*W2][g_ld]
+    float* slab;            // per workgroup partial results
+    int out_ld, out_choff, g_ld, g_choff;
+    int B, H, W, H2, W2, Wb;   // Wb = W / 32
+    long long nunits;
+    float slope;
+};
+
+__device__ __forceinline__ float xor1(float v) {   // value of the neighbouring lane (lane ^ 1)
+    int i = __builtin_bit_cast(int, v);
+    i = __builtin_amdgcn_update_dpp(i, i, 0xB1, 0xF, 0xF, false);   // quad_perm [1, 0, 3, 2]
+    return __builtin_bit_cast(float, i);
+}
+
+__device__ __forceinline__ h4_t lo4(h8_t v) { return h4_t{v[0], v[1], v[2], v[3]}; }
+
+// Position of a work unit (image b, unit row h, 32-column block w) in 32-bit arithmetic, stepped incrementally: a
+// 64-bit decode of the unit index per step cost more instructions than the step's MFMAs.
+struct UnitPos {
+    int b, h, w;
+};
+__device__ __forceinline__ UnitPos unit_decode(int u, int Wb, int Hn) {
+    UnitPos p;
+    p.w = u % Wb;
+    const int t = u / Wb;
+    p.h = t % Hn;
+    p.b = t / Hn;
+    return p;
+}
+__device__ __forceinline__ void unit_advance(UnitPos& p, const UnitPos& d, int Wb, int Hn) {   // p += d (d < one image row range)
+    p.w += d.w;
+    if (p.w >= Wb) p.w -= Wb, ++p.h;
+    p.h += d.h;
+    if (p.h >= Hn) p.h -= Hn, ++p.b;
+    p.b += d.b;
+}
+
+constexpr int XROW = 272;      // bytes of one staged window row: 34 pixels x 8 bytes
+constexpr int GD_BYTES = 2048; // one 32-pixel x 32-filter fp16 tile
+
+// Window rows from the registers that feed the forward MFMAs into LDS, with channel 3 of every INTERIOR pixel set to
+// 1.0 (the NHWC4 image keeps 0 there): column (tap, 3) of the Gram matrix then holds the plain sums S.
+// Lane (pl, kg) holds pixels pl + 2 kg, pl + 2 kg + 1 of each row; lanes kg = 0 cover pixels 0-31, lane (30, 1) 32-33.
+template <int NR>
+__device__ __forceinline__ void stage_window(char* win, const h8_t (&xr)[NR], int pl, int kg, int prow0, int pcol0, int H,
+                                             int W, bool ones) {
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        h8_t v = xr[rr];
+        if (ones) {
+            const bool rin = prow0 + rr >= 1 && prow0 + rr <= H;
+            const int c0 = pcol0 + pl + 2 * kg;
+            v[3] = (rin && c0 >= 1 && c0 <= W) ? (half_t)1.f : (half_t)0.f;
+            v[7] = (rin && c0 + 1 >= 1 && c0 + 1 <= W) ? (half_t)1.f : (half_t)0.f;
+        }
+        if (kg == 0) *(h4_t*)(win + rr * XROW + pl * 8) = lo4(v);
+        else if (pl == 30) *(h8_t*)(win + rr * XROW + 32 * 8) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Gram matrix of the image windows.  A step = 32 consecutive output pixels of one row; its window (3 rows x 34 pixels)
+// goes to LDS and the MFMA fragments are gathered with the transposing read exactly as in wgrad_stem_kernel: F01 =
+// columns (ty in {0, 1}) x (tx, c), F2 = ty = 2.  C = F^T F: the SAME registers serve as the A and the B operand
+// (A[i][k] = F[k][i]).  Slab per workgroup: fp32 [48][48], slot = ty*16 + tx*4 + c (tx = 3 is a don't-care column).
+__global__ __launch_bounds__(512) void stem_gram_kernel(StemBlockArgs a) {
+    constexpr int PERW = 1024, NW = 8;
+    __shared__ __attribute__((aligned(16))) char smem[NW * 16 * 64 * 4];   // the final reduction needs 32 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 31, kg = lane >> 5;
+    char* my = smem + wave * PERW;
+    const unsigned my_addr = lds_addr_of(my);
+    if (lane < 52) *(int*)(my + 816 + lane * 4) = 0;        // bytes the fragment reads touch past the staged window
+    const int g4 = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int krow = 8 * (g4 >> 1) + q;
+    const unsigned b01 = my_addr + (g4 & 1) * XROW + (krow + p) * 8;
+    const unsigned b2 = my_addr + 2 * XROW + (krow + p) * 8;
+
+    f32x16_t cbb, cbc, ccc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cbb[r] = cbc[r] = ccc[r] = 0.f;
+
+    // a wave takes batches of GD consecutive steps; all loads of a batch are in flight before its first window is staged
+    constexpr int GD = 4;
+    const int nunits = (int)a.nunits;
+    const int wstride = gridDim.x * NW * GD;
+    int u0 = (blockIdx.x * NW + wave) * GD;
+    UnitPos pos = unit_decode(u0 < nunits ? u0 : 0, a.Wb, a.H);
+    const UnitPos dstep = unit_decode(wstride - (GD - 1), a.Wb, a.H), one = {0, 0, 1};
+    const int row_elems = (a.W + 2) * 4;
+    for (; u0 < nunits; u0 += wstride) {
+        h8_t xr[GD][3];
+        int uh[GD], uw[GD];
+#pragma unroll
+        for (int d = 0; d < GD; ++d) {
+            uh[d] = pos.h, uw[d] = pos.w;
+            const half_t* px = a.x + ((long long)(pos.b * (a.H + 2) + pos.h) * (a.W + 2) + pos.w * 32 + pl + 2 * kg) * 4;
+            if (u0 + d < nunits) {
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) xr[d][rr] = *(const h8_t*)(px + rr * row_elems);
+            }
+            if (d + 1 < GD) unit_advance(pos, one, a.Wb, a.H);
+        }
+        unit_advance(pos, dstep, a.Wb, a.H);
+#pragma unroll
+        for (int d = 0; d < GD; ++d) {
+            if (u0 + d < nunits) {          // wave-uniform
+                stage_window<3>(my, xr[d], pl, kg, uh[d], uw[d] * 32, a.H, a.W, true);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                Frag fb[2], fc[2];
+                fb[0].lo = tr_read4<0>(b01), fb[0].hi = tr_read4<4 * 8>(b01);
+                fc[0].lo = tr_read4<0>(b2), fc[0].hi = tr_read4<4 * 8>(b2);
+                fb[1].lo = tr_read4<16 * 8>(b01), fb[1].hi = tr_read4<16 * 8 + 4 * 8>(b01);
+                fc[1].lo = tr_read4<16 * 8>(b2), fc[1].hi = tr_read4<16 * 8 + 4 * 8>(b2);
+                lds_wait_all(fb[0]);
+#pragma unroll
+                for (int k16 = 0; k16 < 2; ++k16) {
+                    tie(fb[k16]), tie(fc[k16]);
+                    cbb = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[k16].v(), fb[k16].v(), cbb, 0, 0, 0);
+                    cbc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[k16].v(), fc[k16].v(), cbc, 0, 0, 0);
+                    ccc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fc[k16].v(), fc[k16].v(), ccc, 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // sum the waves in a fixed order, one accumulator at a time: red[wave][r][lane]; D[row i][col j], i / j = fragment
+    // columns.  (fp32 throughout: measured at B=64 the batch mean / invstd derived from C are within 1.2e-7 of float64.)
+    float* red = (float*)smem;
+    float* out = a.slab + (long long)blockIdx.x * 2304;
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = which == 0 ? cbb[r] : (which == 1 ? cbc[r] : ccc[r]);
+        __syncthreads();
+        for (int idx = tid; idx < 1024; idx += 512) {
+            float v = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) v += red[wv * 1024 + idx];
+            const int r = idx >> 6, ln = idx & 63;
+            const int i = mfma32_row(r, ln), j = ln & 31;
+            if (which == 0) out[i * 48 + j] = v;
+            else if (which == 1) {
+                if (j < 16) out[i * 48 + 32 + j] = v, out[(32 + j) * 48 + i] = v;
+            } else if (i < 16 && j < 16) out[(32 + i) * 48 + 32 + j] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// out[e] = sum over slabs of slab[s][e], in double, fixed order (16 groups of slabs per entry, combined through LDS)
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* slab, int nslabs, int n, double* out) {
+    __shared__ double red[16][16];
+    const int e16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + e16;
+    double s = 0.0;
+    if (e < n)
+        for (int k = grp; k < nslabs; k += 16) s += (double)slab[(long long)k * n + e];
+    red[grp][e16] = s;
+    __syncthreads();
+    if (grp == 0 && e < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][e16];
+        out[e] = t;
+    }
+}
+
+__device__ __forceinline__ int slot48(int ty, int tx, int c) { return ty * 16 + tx * 4 + c; }
+
+// Batch statistics of y = W v from the Gram matrix -> BatchNorm coefficients; keeps S and W C for the backward pass.
+// ctx (double): [0, 27) S, [32, 32 + 32*27) (W C)[n][k27], k27 = (ty*3 + tx)*3 + c.
+__global__ __launch_bounds__(1024) void stem_coeffs_kernel(const double* csum, const half_t* wp, double count, const float* gamma,
+                                                           const float* beta, float* rmean, float* rvar, float momentum,
+                                                           float eps, float* scale, float* shift, float* save_mean,
+                                                           float* save_invstd, double* ctx) {
+    __shared__ double C[48 * 48];
+    __shared__ double Wd[32][28], WC[32][28], S[28];
+    const int t = threadIdx.x;
+    for (int i = t; i < 2304; i += 1024) C[i] = csum[i];
+    if (t < 864) {
+        const int n = t / 27, k = t - n * 27;
+        const int ty = k / 9, tx = (k / 3) % 3, c = k % 3;
+        Wd[n][k] = (double)(float)wp[n * 96 + ty * 32 + tx * 4 + c];
+    }
+    __syncthreads();
+    if (t < 27) {
+        const int ty = t / 9, tx = (t / 3) % 3, c = t % 3;
+        S[t] = C[slot48(ty, tx, c) * 48 + slot48(ty, tx, 3)];
+        ctx[t] = S[t];
+    }
+    if (t < 864) {
+        const int n = t / 27, k = t - n * 27;
+        const int sk = slot48(k / 9, (k / 3) % 3, k % 3);
+        double acc = 0.0;
+        for (int k2 = 0; k2 < 27; ++k2) acc += Wd[n][k2] * C[slot48(k2 / 9, (k2 / 3) % 3, k2 % 3) * 48 + sk];
+        WC[n][k] = acc;
+        ctx[32 + n * 27 + k] = acc;
+    }
+    __syncthreads();
+    if (t < 32) {
+        double m1 = 0.0, m2 = 0.0;
+        for (int k = 0; k < 27; ++k) {
+            m1 += Wd[t][k] * S[k];
+            m2 += Wd[t][k] * WC[t][k];
+        }
+        const double mean = m1 / count;
+        double var = m2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double invstd = 1.0 / sqrt(var + (double)eps);
+        const double sc = (double)gamma[t] * invstd;
+        scale[t] = (float)sc;
+        shift[t] = (float)((double)beta[t] - mean * sc);
+        save_mean[t] = (float)mean;
+        save_invstd[t] = (float)invstd;
+        if (rmean) rmean[t] = (float)((1.0 - momentum) * (double)rmean[t] + momentum * mean);
+        if (rvar) rvar[t] = (float)((1.0 - momentum) * (double)rvar[t] + momentum * var * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward: a unit = 32 columns x 2 rows of the conv output = 16 pooled pixels.  Y^T = W X^T as in stem_fwd_kernel
+// (accumulator lane = pixel, registers = channels), four image rows per unit feed both conv rows; the 2x2 window is
+// a register pair (rows) and a lane pair (columns).  LeakyReLU is monotonic, so it is applied to the window maximum.
+template <int UN>
+__global__ __launch_bounds__(256) void stem_block_fwd_kernel(StemBlockArgs a) {
+    __shared__ __attribute__((aligned(16))) half_t tile[4][16 * 32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 31, kg = lane >> 5;
+    h8_t wf[3];
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) wf[ty] = *(const h8_t*)(a.w + (long long)pl * 96 + ty * 32 + 8 * kg);
+    float sc[16], sh[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ch = (r & 3) + 8 * (r >> 2) + 4 * kg;
+        sc[r] = a.scale[ch];
+        sh[r] = a.shift[ch];
+    }
+    half_t* tw = tile[wave];
+    const bool odd = pl & 1;
+    const int nunits = (int)a.nunits;
+    const int wstride = gridDim.x * 4 * UN;
+    int u0 = (blockIdx.x * 4 + wave) * UN;
+    UnitPos pos = unit_decode(u0 < nunits ? u0 : 0, a.Wb, a.H2);
+    const UnitPos dstep = unit_decode(wstride - (UN - 1), a.Wb, a.H2), one = {0, 0, 1};
+    const int row_elems = (a.W + 2) * 4;
+    for (; u0 < nunits; u0 += wstride) {
+        h8_t xr[UN][4];
+        int ub[UN], uh[UN], uw[UN];
+#pragma unroll
+        for (int i = 0; i < UN; ++i) {
+            ub[i] = pos.b, uh[i] = pos.h, uw[i] = pos.w;
+            const half_t* px = a.x + ((long long)(pos.b * (a.H + 2) + 2 * pos.h) * (a.W + 2) + pos.w * 32 + pl + 2 * kg) * 4;
+            if (u0 + i < nunits) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) xr[i][rr] = *(const h8_t*)(px + rr * row_elems);
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) xr[i][rr] = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+            if (i + 1 < UN) unit_advance(pos, one, a.Wb, a.H2);
+        }
+        unit_advance(pos, dstep, a.Wb, a.H2);
+#pragma unroll
+        for (int i = 0; i < UN; ++i) {
+            f32x16_t acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ty], xr[i][ty], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ty], xr[i][ty + 1], acc1, 0, 0, 0);
+            }
+            float av[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float z0 = __builtin_fmaf(acc0[r], sc[r], sh[r]), z1 = __builtin_fmaf(acc1[r], sc[r], sh[r]);
+                float m = fmaxf(z0, z1);
+                m = fmaxf(m, xor1(m));
+                m = m > 0.f ? m : m * a.slope;
+                av[r] = fminf(fmaxf(m, -65504.f), 65504.f);
+            }
+            // both lanes of a column pair hold the pooled pixel pl >> 1: the even lane writes channel groups j = 0, 1,
+            // the odd lane j = 2, 3 (channels 8 j + 4 kg .. + 3)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                h4_t v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (half_t)(odd ? av[8 + 4 * jj + e] : av[4 * jj + e]);
+                *(h4_t*)(tw + (pl >> 1) * 32 + 8 * ((odd ? 2 : 0) + jj) + 4 * kg) = v;
+            }
+            const int prow = lane >> 2, pc = lane & 3;
+            const h8_t v = *(const h8_t*)(tw + prow * 32 + pc * 8);
+            if (u0 + i < nunits)
+                *(h8_t*)(a.out + ((long long)(ub[i] * (a.H2 + 2) + uh[i] + 1) * (a.W2 + 2) + uw[i] * 16 + prow + 1) * a.out_ld +
+                         a.out_choff + pc * 8) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward: per unit recompute both conv rows, find the window argmax (first maximum in (h, w) scan order, torch's
+// max_pool2d rule), route G * leaky'(z) to it, and accumulate T = Gd^T V with the fragments of wgrad_stem_kernel:
+// the 32-pixel x 32-filter tiles Gd of the two rows are written to LDS from the registers, the window rows too.
+// Slab per workgroup: fp32 [32][96] (T in the stem K layout) + [32] (dbeta).
+template <int A_OFF, int B_OFF>
+__device__ __forceinline__ void bwd_frags(unsigned a_addr, unsigned b01, unsigned b2, Frag& fa, Frag& fb, Frag& fc) {
+    fa.lo = tr_read4<A_OFF>(a_addr), fa.hi = tr_read4<A_OFF + 4 * 64>(a_addr);
+    fb.lo = tr_read4<B_OFF>(b01), fb.hi = tr_read4<B_OFF + 4 * 8>(b01);
+    fc.lo = tr_read4<B_OFF>(b2), fc.hi = tr_read4<B_OFF + 4 * 8>(b2);
+}
+
+__global__ __launch_bounds__(512) void stem_block_bwd_kernel(StemBlockArgs a) {
+    constexpr int WIN = 1152, PERW = 2 * GD_BYTES + WIN, NW = 8;    // 5248 bytes per wave
+    __shared__ __attribute__((aligned(16))) char smem[NW * PERW];
+    static_assert(NW * PERW >= NW * 16 * 64 * 4, "reduction buffer");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 31, kg = lane >> 5;
+    char* my = smem + wave * PERW;
+    const unsigned my_addr = lds_addr_of(my);
+    if (lane < 16) *(int*)(my + 2 * GD_BYTES + 4 * XROW + lane * 4) = 0;
+    h8_t wf[3];
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) wf[ty] = *(const h8_t*)(a.w + (long long)pl * 96 + ty * 32 + 8 * kg);
+    float sc[16], sh[16], sb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ch = (r & 3) + 8 * (r >> 2) + 4 * kg;
+        sc[r] = a.scale[ch];
+        sh[r] = a.shift[ch];
+        sb[r] = 0.f;
+    }
+    f32x16_t t01, t2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t01[r] = t2[r] = 0.f;
+    const int g4 = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int krow = 8 * (g4 >> 1) + q;
+    const unsigned a_addr = my_addr + krow * 64 + (16 * (g4 & 1) + 4 * p) * 2;
+    const unsigned b01 = my_addr + 2 * GD_BYTES + (g4 & 1) * XROW + (krow + p) * 8;
+    const unsigned b2 = my_addr + 2 * GD_BYTES + 2 * XROW + (krow + p) * 8;
+    const bool odd = pl & 1;
+
+    // one unit per iteration; the image rows and G of the NEXT unit are loaded before the current one is processed
+    const int nunits = (int)a.nunits;
+    const int wstride = gridDim.x * NW;
+    const int row_elems = (a.W + 2) * 4;
+    h8_t xn[4];
+    h4_t gn[4];
+    int u = blockIdx.x * NW + wave;
+    UnitPos pos = unit_decode(u < nunits ? u : 0, a.Wb, a.H2);
+    const UnitPos dstep = unit_decode(wstride, a.Wb, a.H2);
+    auto fetch = [&]() {
+        const half_t* px = a.x + ((long long)(pos.b * (a.H + 2) + 2 * pos.h) * (a.W + 2) + pos.w * 32 + pl + 2 * kg) * 4;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) xn[rr] = *(const h8_t*)(px + rr * row_elems);
+        const half_t* gp = a.g + ((long long)(pos.b * a.H2 + pos.h) * a.W2 + pos.w * 16 + (pl >> 1)) * a.g_ld + a.g_choff + 4 * kg;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gn[j] = *(const h4_t*)(gp + 8 * j);
+    };
+    if (u < nunits) fetch();
+    for (; u < nunits; u += wstride) {
+        h8_t xr[4];
+        h4_t gq[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) xr[rr] = xn[rr];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gq[j] = gn[j];
+        const int h2 = pos.h, wb = pos.w;
+        unit_advance(pos, dstep, a.Wb, a.H2);
+        if (u + wstride < nunits) fetch();
+
+        f32x16_t acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ty], xr[ty], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ty], xr[ty + 1], acc1, 0, 0, 0);
+        }
+        stage_window<4>(my + 2 * GD_BYTES, xr, pl, kg, 2 * h2, wb * 32, a.H, a.W, false);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h4_t d0, d1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * j + e;
+                const float z0 = __builtin_fmaf(acc0[r], sc[r], sh[r]), z1 = __builtin_fmaf(acc1[r], sc[r], sh[r]);
+                const float o0 = xor1(z0), o1 = xor1(z1);
+                // the window in scan order: (row 0, col 0), (0, 1), (1, 0), (1, 1); this lane is column `odd`
+                const float v0 = odd ? o0 : z0, v1 = odd ? z0 : o0, v2 = odd ? o1 : z1, v3 = odd ? z1 : o1;
+                float best = v0;
+                int arg = 0;
+                if (v1 > best) best = v1, arg = 1;
+                if (v2 > best) best = v2, arg = 2;
+                if (v3 > best) best = v3, arg = 3;
+                const float gz = (float)gq[j][e] * (best > 0.f ? 1.f : a.slope);
+                const float e0 = arg == (odd ? 1 : 0) ? gz : 0.f, e1 = arg == (odd ? 3 : 2) ? gz : 0.f;
+                sb[r] += e0 + e1;
+                d0[e] = (half_t)e0;
+                d1[e] = (half_t)e1;
+            }
+            *(h4_t*)(my + pl * 64 + (8 * j + 4 * kg) * 2) = d0;
+            *(h4_t*)(my + GD_BYTES + pl * 64 + (8 * j + 4 * kg) * 2) = d1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        Frag fa[4], fb[4], fc[4];
+        bwd_frags<0, 0>(a_addr, b01, b2, fa[0], fb[0], fc[0]);                                   // row 0, pixels 0-15
+        bwd_frags<16 * 64, 16 * 8>(a_addr, b01, b2, fa[1], fb[1], fc[1]);                        // row 0, pixels 16-31
+        bwd_frags<GD_BYTES, XROW>(a_addr, b01, b2, fa[2], fb[2], fc[2]);                         // row 1
+        bwd_frags<GD_BYTES + 16 * 64, XROW + 16 * 8>(a_addr, b01, b2, fa[3], fb[3], fc[3]);
+        lds_wait_all(fa[0]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            tie(fa[s]), tie(fb[s]), tie(fc[s]);
+            t01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s].v(), fb[s].v(), t01, 0, 0, 0);
+            t2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s].v(), fc[s].v(), t2, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    float* red = (float*)smem;
+    float* out = a.slab + (long long)blockIdx.x * 3104;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = which == 0 ? t01[r] : t2[r];
+        __syncthreads();
+        for (int idx = tid; idx < 1024; idx += 512) {
+            float v = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) v += red[wv * 1024 + idx];
+            const int r = idx >> 6, ln = idx & 63;
+            const int n = mfma32_row(r, ln), col = ln & 31;
+            if (which == 0) out[n * 96 + (col >> 4) * 32 + (col & 15)] = v;
+            else if (col < 16) out[n * 96 + 64 + col] = v;
+        }
+        __syncthreads();
+    }
+    // dbeta: lanes with the same kg hold the same channels
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = sb[r];
+#pragma unroll
+        for (int msk = 1; msk < 32; msk <<= 1) v += __shfl_xor(v, msk);
+        if (pl == 0) red[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg] = v;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) v += red[wv * 32 + tid];
+        out[3072 + tid] = v;
+    }
+    // columns the accumulators do not cover (tx slots 4-7 of every filter row) are never read
+}
+
+// tsum (double [3104]) -> dW (OIHW, x mask), dgamma, dbeta; see the file header.
+__global__ __launch_bounds__(1024) void stem_bwd_finish_kernel(const double* tsum, const double* ctx, const half_t* wp,
+                                                               double count, const float* gamma, const float* save_mean,
+                                                               const float* save_invstd, const float* mask, double inv_scale,
+                                                               float* dw, float* dgamma, float* dbeta) {
+    __shared__ double Wd[32][28], T[32][28], dB[32], dG[32];
+    const int t = threadIdx.x;
+    if (t < 864) {
+        const int n = t / 27, k = t - n * 27;
+        const int ty = k / 9, tx = (k / 3) % 3, c = k % 3;
+        Wd[n][k] = (double)(float)wp[n * 96 + ty * 32 + tx * 4 + c];
+        T[n][k] = tsum[n * 96 + ty * 32 + tx * 4 + c] * inv_scale;
+    }
+    if (t < 32) dB[t] = tsum[3072 + t] * inv_scale;
+    __syncthreads();
+    if (t < 32) {
+        double acc = 0.0;
+        for (int k = 0; k < 27; ++k) acc += Wd[t][k] * T[t][k];
+        dG[t] = (double)save_invstd[t] * (acc - (double)save_mean[t] * dB[t]);
+        if (dbeta) dbeta[t] = (float)dB[t];
+        if (dgamma) dgamma[t] = (float)dG[t];
+    }
+    __syncthreads();
+    if (t < 864) {
+        const int n = t / 27, k = t - n * 27;
+        const int ty = k / 9, tx = (k / 3) % 3, c = k % 3;
+        const double istd = (double)save_invstd[n], mu = (double)save_mean[n];
+        const double S = ctx[k], WC = ctx[32 + n * 27 + k];
+        double v = (double)gamma[n] * istd * (T[n][k] - dB[n] / count * S - dG[n] / count * istd * (WC - mu * S));
+        const int dst = ((n * 3 + c) * 3 + ty) * 3 + tx;
+        if (mask) v *= (double)mask[dst];
+        dw[dst] = (float)v;
+    }
+}
+
+struct Carve {      // workspace layout (bytes), all offsets multiples of 256
+    size_t gram_slab, gram_sum, ctx, bwd_slab, bwd_sum, total;
+};
+constexpr int kGramWgs = 256, kBwdWgs = 256;   // one 8-wave workgroup per CU
+Carve carve() {
+    Carve c;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    c.gram_slab = take((size_t)kGramWgs * 2304 * sizeof(float));
+    c.gram_sum = take(2304 * sizeof(double));
+    c.ctx = take((32 + 32 * 27) * sizeof(double));
+    c.bwd_slab = take((size_t)kBwdWgs * 3104 * sizeof(float));
+    c.bwd_sum = take(3104 * sizeof(double));
+    c.total = off;
+    return c;
+}
+
+int check_desc(const mcamd_stem_block_desc* d, const char* what) {
+    MCAMD_REQUIRE(d, "%s: null descriptor", what);
+    MCAMD_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0, "%s: non-positive dimension", what);
+    MCAMD_REQUIRE(d->W % 32 == 0 && d->H % 2 == 0, "%s: needs W %% 32 == 0 and an even H (got %d x %d)", what, d->H, d->W);
+    MCAMD_REQUIRE((long long)d->B * d->H * d->W < (1ll << 31), "%s: more than 2^31 output pixels", what);
+    MCAMD_REQUIRE(d->x && d->wp && d->scale && d->shift, "%s: null argument", what);
+    return MCAMD_OK;
+}
+
+void fill_args(StemBlockArgs& a, const mcamd_stem_block_desc* d) {
+    memset(&a, 0, sizeof(a));
+    a.x = (const half_t*)d->x;
+    a.w = (const half_t*)d->wp;
+    a.scale = d->scale, a.shift = d->shift;
+    a.B = d->B, a.H = d->H, a.W = d->W, a.H2 = d->H / 2, a.W2 = d->W / 2, a.Wb = d->W / 32;
+    a.slope = d->slope;
+}
+
+}  // namespace
+
+extern "C" size_t mcamd_stem_block_workspace_bytes(void) { return carve().total; }
+
+extern "C" int mcamd_stem_block_fwd(const mcamd_stem_block_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+    if (check_desc(d, "stem_block_fwd")) return MCAMD_EINVAL;
+    MCAMD_REQUIRE(d->dst && d->dst_ld % 8 == 0 && d->dst_choff % 8 == 0 && d->dst_choff + 32 <= d->dst_ld,
+                  "stem_block_fwd: output slice [%d, %d) does not fit dst_ld %d", d->dst_choff, d->dst_choff + 32, d->dst_ld);
+    const Carve c = carve();
+    hipStream_t st = (hipStream_t)stream;
+    StemBlockArgs a;
+    fill_args(a, d);
+    if (d->training) {
+        MCAMD_REQUIRE(workspace && d->gamma && d->beta && d->save_mean && d->save_invstd, "stem_block_fwd: null argument (training)");
+        if (workspace_bytes < c.total) {
+            mcamd_set_error("stem_block_fwd: workspace %zu < %zu bytes", workspace_bytes, c.total);
+            return MCAMD_EWORKSPACE;
+        }
+        char* ws = (char*)workspace;
+        StemBlockArgs g = a;
+        g.nunits = (long long)d->B * d->H * g.Wb;
+        g.slab = (float*)(ws + c.gram_slab);
+        long long want = (g.nunits + 31) / 32;    // >= one batch of 4 steps per wave
+        const int grid = (int)(want < kGramWgs ? (want < 1 ? 1 : want) : kGramWgs);
+        hipLaunchKernelGGL(stem_gram_kernel, dim3(grid), dim3(512), 0, st, g);
+        MCAMD_LAUNCH_CHECK("stem_gram");
+        hipLaunchKernelGGL(slab_sum_kernel, dim3(2304 / 16), dim3(256), 0, st, (const float*)g.slab, grid, 2304,
+                           (double*)(ws + c.gram_sum));
+        hipLaunchKernelGGL(stem_coeffs_kernel, dim3(1), dim3(1024), 0, st, (const double*)(ws + c.gram_sum), a.w,
+                           (double)d->B * d->H * d->W, d->gamma, d->beta, d->running_mean, d->running_var, d->momentum, d->eps,
+                           d->scale, d->shift, d->save_mean, d->save_invstd, (double*)(ws + c.ctx));
+        MCAMD_LAUNCH_CHECK("stem_coeffs");
+    }
+    a.out = (half_t*)d->dst;
+    a.out_ld = d->dst_ld, a.out_choff = d->dst_choff;
+    a.nunits = (long long)d->B * a.H2 * a.Wb;
+    long long want = (a.nunits + 7) / 8;          // >= one pass of 2 units per wave
+    const int grid = (int)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
+    const char* e_un = getenv("MCAMD_STEM_FWD_UN");   // tuning switch
+    const int un = e_un ? atoi(e_un) : 2;
+    if (un == 4) hipLaunchKernelGGL(stem_block_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, a);
+    else if (un == 1) hipLaunchKernelGGL(stem_block_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(stem_block_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, a);
+    MCAMD_LAUNCH_CHECK("stem_block_fwd");
+    return MCAMD_OK;
+}
+
+extern "C" int mcamd_stem_block_bwd(const mcamd_stem_block_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+    if (check_desc(d, "stem_block_bwd")) return MCAMD_EINVAL;
+    MCAMD_REQUIRE(workspace && d->g && d->dw && d->gamma && d->save_mean && d->save_invstd, "stem_block_bwd: null argument");
+    MCAMD_REQUIRE(d->g_ld % 8 == 0 && d->g_choff % 8 == 0 && d->g_choff + 32 <= d->g_ld,
+                  "stem_block_bwd: gradient slice [%d, %d) does not fit g_ld %d", d->g_choff, d->g_choff + 32, d->g_ld);
+    MCAMD_REQUIRE(d->grad_scale > 0.f, "stem_block_bwd: grad_scale must be positive");
+    const Carve c = carve();
+    if (workspace_bytes < c.total) {
+        mcamd_set_error("stem_block_bwd: workspace %zu < %zu bytes", workspace_bytes, c.total);
+        return MCAMD_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    StemBlockArgs a;
+    fill_args(a, d);
+    a.g = (const half_t*)d->g;
+    a.g_ld = d->g_ld, a.g_choff = d->g_choff;
+    a.nunits = (long long)d->B * a.H2 * a.Wb;
+    a.slab = (float*)(ws + c.bwd_slab);
+    long long want = (a.nunits + 31) / 32;        // >= 4 units per wave
+    const int grid = (int)(want < kBwdWgs ? (want < 1 ? 1 : want) : kBwdWgs);
+    hipLaunchKernelGGL(stem_block_bwd_kernel, dim3(grid), dim3(512), 0, st, a);
+    MCAMD_LAUNCH_CHECK("stem_block_bwd");
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(3104 / 16), dim3(256), 0, st, (const float*)a.slab, grid, 3104,
+                       (double*)(ws + c.bwd_sum));
+    hipLaunchKernelGGL(stem_bwd_finish_kernel, dim3(1), dim3(1024), 0, st, (const double*)(ws + c.bwd_sum),
+                       (const double*)(ws + c.ctx), a.w, (double)d->B * d->H * d->W, d->gamma, d->save_mean, d->save_invstd,
+                       d->mask, 1.0 / (double)d->grad_scale, d->dw, d->dgamma, d->dbeta);
+    MCAMD_LAUNCH_CHECK("stem_bwd_finish");
+    return MCAMD_OK;
+}

@@ -289,7 +289,12 @@ class Engine:
             lay.wd = torch.zeros(nd, dtype=ops.HALF, device=dev) if (nd and lay.li > 0) else None
             wbytes = max(wbytes, ops.wgrad_workspace_bytes(g))
             lay.cout_p = ops.round_up(lay.cout, 32)
-            lay.dy = ops.alloc_padded(B, lay.H, lay.W, lay.cout_p, dev)
+            # the first block as one unit (conv1 + BN + LeakyReLU + maxpool, csrc/conv_stem_block.hip): neither its raw
+            # output (709 MB at B=64) nor the gradient wrt it is ever stored
+            lay.fused_stem = bool(lay.stem and lay.bn is not None and lay.mode == L.DST_POOL and lay.out2_id is None
+                                  and lay.cout == 32 and lay.W % 32 == 0 and lay.H % 2 == 0 and lay.border is None
+                                  and os.environ.get("MCAMD_STEM_FUSED", "1") == "1")
+            lay.dy = None if lay.fused_stem else ops.alloc_padded(B, lay.H, lay.W, lay.cout_p, dev)
             lay.keep, lay.keep_key = None, None
             lay.gin = None
             if lay.li > 0:
@@ -297,10 +302,14 @@ class Engine:
             lay.perm = lay.perm32 = lay.in_perm = lay.g_rows = lay.g_cols = None
             lay.n_act, lay.geom_act, lay.gather = lay.cout, lay.geom, False
             if not lay.is_last:
-                # zero-initialised: with filter compaction the convolution writes the kept channels only
-                lay.y = torch.zeros(lay.M * lay.cout, dtype=torch.float32 if self.precise else ops.HALF, device=dev)
-                lay.stats = torch.zeros(ops.stats_rows(lay.geom_f, L.EPI_RAW_F32 if self.precise else L.EPI_RAW_F16), 2,
-                                        ops.round_up(lay.cout, 256), **f32)
+                if lay.fused_stem:
+                    lay.y = lay.stats = None
+                    lay.stem_ws = torch.empty(ops.stem_block_workspace_bytes(), dtype=torch.uint8, device=dev)
+                else:
+                    # zero-initialised: with filter compaction the convolution writes the kept channels only
+                    lay.y = torch.zeros(lay.M * lay.cout, dtype=torch.float32 if self.precise else ops.HALF, device=dev)
+                    lay.stats = torch.zeros(ops.stats_rows(lay.geom_f, L.EPI_RAW_F32 if self.precise else L.EPI_RAW_F16), 2,
+                                            ops.round_up(lay.cout, 256), **f32)
                 lay.scale, lay.shift, lay.mean, lay.invstd = (torch.empty(lay.cout, **f32) for _ in range(4))
                 lay.out_t = place.get(lay.out_id)
                 lay.out2_t = place.get(lay.out2_id) if lay.out2_id is not None else None
@@ -481,7 +490,7 @@ class Engine:
                 lay.gather = perm is not None or in_perm is not None
                 lay.g_rows = perm[:n_act].to(torch.int32).contiguous() if perm is not None else None
                 lay.g_cols = in_perm.to(torch.int32).contiguous() if in_perm is not None else None
-                if lay.bn is not None and not self.precise:
+                if lay.bn is not None and not self.precise and not lay.fused_stem:
                     rows = ops.stats_rows(lay.geom_act)
                     if lay.stats.shape[0] != rows:
                         lay.stats = torch.zeros(rows, 2, lay.stats.shape[2], dtype=torch.float32, device=dev)
@@ -542,6 +551,18 @@ class Engine:
                     out += lay.border_map
                 continue
             bn = lay.bn
+            if lay.fused_stem:
+                # conv1 + BatchNorm + LeakyReLU + maxpool in one pass over the image (batch statistics from the Gram
+                # matrix of the image windows in training mode, running statistics otherwise)
+                if not training:
+                    ops.bn_coeffs(None, lay.cout, lay.M, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, False,
+                                  lay.scale, lay.shift, lay.mean, lay.invstd, eps=bn.eps)
+                t = lay.out_t
+                self._timed('fwd', lay, ops.stem_block_fwd, B, lay.H, lay.W, xin, lay.wp, bn.weight.data, bn.bias.data,
+                            bn.running_mean, bn.running_var, training, lay.scale, lay.shift, lay.mean, lay.invstd, lay.slope,
+                            self.bufs[t.buf], t.ld, t.choff, lay.stem_ws,
+                            momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps)
+                continue
             if self.precise:
                 # unrounded fp32 raw output (+ batch statistics from the fp32 values), then BN + LeakyReLU
                 # (+ pool / reorg / route) written as hi | lo | hi planes
@@ -606,6 +627,24 @@ class Engine:
                 self._side_ws = torch.empty(self.wgrad_ws.numel(), dtype=torch.uint8, device=self.device)
                 self._side_ws.record_stream(side)
         for lay in reversed(self.layers):
+            if lay.fused_stem:
+                # the whole backward of the first block in one pass over the image and G (conv_stem_block.hip)
+                cons = self.consumer_of[lay.out_id]
+                mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
+                self._timed('wgrad', lay, ops.stem_block_bwd, self.B, lay.H, lay.W, self.bufs[lay.tin.buf], lay.wp,
+                            lay.bn.weight.data, lay.scale, lay.shift, lay.mean, lay.invstd, lay.slope, cons.gin, cons.tin.ld,
+                            lay.out_t.choff, gmap[id(lay.conv.weight)], gmap[id(lay.bn.weight)], gmap[id(lay.bn.bias)],
+                            lay.stem_ws, mask=mask, grad_scale=S)
+                if on_ready is not None:
+                    if side is None:
+                        on_ready(flat, lay.p_lo, lay.p_hi)
+                    else:
+                        ev2 = torch.cuda.Event()
+                        ev2.record(main)
+                        side.wait_event(ev2)
+                        with torch.cuda.stream(side):
+                            on_ready(flat, lay.p_lo, lay.p_hi)
+                continue
             if lay.is_last:
                 ops.nchw_to_padded(grad_out.detach().contiguous().float(), lay.dy, lay.cout_p, 0, S, overflow=self.overflow)
             else:

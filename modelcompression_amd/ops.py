@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from ._lib import ConvGeom, ConvEpilogue, ActDesc, ActBwdDesc, ChanMap, PackJob, check, ptr, stream_ptr
+from ._lib import ConvGeom, ConvEpilogue, ActDesc, ActBwdDesc, ChanMap, PackJob, StemBlockDesc, check, ptr, stream_ptr
 
 HALF = torch.float16
 SLACK = 64  # fp16 elements of zeroed slack after every activation buffer
@@ -252,6 +252,53 @@ def bn_act_bwd_workspace_bytes(C_):
     d = ActBwdDesc()
     d.C = C_
     return int(L.lib().mcamd_bn_act_bwd_workspace_bytes(C.byref(d)))
+
+
+def stem_block_workspace_bytes():
+    return int(L.lib().mcamd_stem_block_workspace_bytes())
+
+
+def _stem_desc(B, H, W, x, wp, gamma, beta, scale, shift, mean, invstd, slope):
+    _need_cuda(x, wp, scale, shift)
+    d = StemBlockDesc()
+    d.B, d.H, d.W = B, H, W
+    d.x, d.wp = x.data_ptr(), wp.data_ptr()
+    d.gamma = gamma.data_ptr() if gamma is not None else None
+    d.beta = beta.data_ptr() if beta is not None else None
+    d.scale, d.shift = scale.data_ptr(), shift.data_ptr()
+    d.save_mean = mean.data_ptr() if mean is not None else None
+    d.save_invstd = invstd.data_ptr() if invstd is not None else None
+    d.slope = slope
+    return d
+
+
+def stem_block_fwd(B, H, W, x, wp, gamma, beta, rmean, rvar, training, scale, shift, mean, invstd, slope, dst, dst_ld,
+                   dst_choff, workspace, momentum=0.1, eps=1e-5):
+    """The first block in one call: conv1 (3 -> 32, 3x3) + BatchNorm + LeakyReLU + MaxPool(2,2) from the NHWC4 image
+    `x` to the pooled padded-NHWC `dst`; the raw conv output is never stored (include/mcamd.h, mcamd_stem_block_desc).
+    training: batch statistics from the image windows' Gram matrix, scale / shift / mean / invstd are written."""
+    d = _stem_desc(B, H, W, x, wp, gamma, beta, scale, shift, mean, invstd, slope)
+    d.running_mean = rmean.data_ptr() if rmean is not None else None
+    d.running_var = rvar.data_ptr() if rvar is not None else None
+    d.momentum, d.eps, d.training = momentum, eps, 1 if training else 0
+    d.dst, d.dst_ld, d.dst_choff = dst.data_ptr(), dst_ld, dst_choff
+    check(L.lib().mcamd_stem_block_fwd(C.byref(d), ptr(workspace), workspace.numel() if workspace is not None else 0,
+                                       stream_ptr()), "mcamd_stem_block_fwd")
+
+
+def stem_block_bwd(B, H, W, x, wp, gamma, scale, shift, mean, invstd, slope, g, g_ld, g_choff, dw, dgamma, dbeta, workspace,
+                   mask=None, grad_scale=1.0):
+    """Backward of stem_block_fwd (training mode) from the gradient `g` wrt the pooled output: dW (OIHW, x mask),
+    dgamma, dbeta.  `workspace` must be the one the forward call of this step used."""
+    _need_cuda(g, dw)
+    d = _stem_desc(B, H, W, x, wp, gamma, None, scale, shift, mean, invstd, slope)
+    d.g, d.g_ld, d.g_choff = g.data_ptr(), g_ld, g_choff
+    d.mask = mask.data_ptr() if mask is not None else None
+    d.grad_scale = grad_scale
+    d.dw = dw.data_ptr()
+    d.dgamma = dgamma.data_ptr() if dgamma is not None else None
+    d.dbeta = dbeta.data_ptr() if dbeta is not None else None
+    check(L.lib().mcamd_stem_block_bwd(C.byref(d), ptr(workspace), workspace.numel(), stream_ptr()), "mcamd_stem_block_bwd")
 
 
 def nchw_to_padded(src, dst, dst_ld, dst_choff=0, mul=1.0, overflow=None):

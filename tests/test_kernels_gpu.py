@@ -335,6 +335,73 @@ def test_wgrad_stem(dev, B, H, W):
     assert rel_l2(dw.cpu(), w.grad) < TOL
 
 
+@pytest.mark.parametrize("B,H,W,masked,training", [(2, 32, 64, False, True), (3, 46, 96, True, True), (1, 64, 32, False, True),
+                                                     (2, 32, 64, False, False)])
+def test_stem_block_fwd_bwd(dev, B, H, W, masked, training):
+    """conv1 + BatchNorm + LeakyReLU + MaxPool(2,2) as one unit (csrc/conv_stem_block.hip: batch statistics from the
+    Gram matrix of the image windows, no raw output, algebraic weight gradient) against float64 torch autograd of
+    the four reference ops (nets.py:798-821) on the same fp16-rounded image, weights and output gradient."""
+    cout, S = 32, 8.0
+    gen = torch.Generator().manual_seed(31 + H)
+    x = torch.rand(B, 3, H, W, generator=gen)
+    w = torch.randn(cout, 3, 3, 3, generator=gen) * 0.3
+    mask = (torch.rand(cout, 3, 3, 3, generator=gen) > 0.4).float() if masked else None
+    if masked:
+        mask[5] = 0.0                                          # a fully pruned filter: zero batch variance
+    gamma, beta = torch.rand(cout, generator=gen) + 0.5, torch.randn(cout, generator=gen) * 0.2
+    rm0, rv0 = torch.randn(cout, generator=gen) * 0.1, torch.rand(cout, generator=gen) + 0.5
+    gout = q16(torch.randn(B, cout, H // 2, W // 2, generator=gen) * S) / S
+
+    wl = q16(w * mask if masked else w).double().requires_grad_(True)
+    gl, bl = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm_ref, rv_ref = rm0.double().clone(), rv0.double().clone()
+    y = F.conv2d(q16(x).double(), wl, None, 1, 1)
+    z = F.batch_norm(y, rm_ref, rv_ref, gl, bl, training, 0.1, 1e-5)
+    out = F.max_pool2d(F.leaky_relu(z, 0.1), 2, 2)
+    if training:
+        (out * gout.double()).sum().backward()
+
+    xb, _ = to_padded(x.to(dev))
+    g = ops.geom(B, H, W, 3, 3, cout, 4, 0, stem=1)
+    wp, _ = ops.pack_weights(g, w.to(dev).contiguous(), mask.to(dev) if masked else None)
+    rm, rv = rm0.to(dev), rv0.to(dev)
+    scale, shift, mean, invstd = (torch.empty(cout, device=dev) for _ in range(4))
+    ws = torch.empty(ops.stem_block_workspace_bytes(), dtype=torch.uint8, device=dev)
+    ld = 64
+    dst = ops.alloc_padded(B, H // 2, W // 2, ld, dev)
+    if not training:
+        ops.bn_coeffs(None, cout, 1, gamma.to(dev), beta.to(dev), rm, rv, False, scale, shift)
+    ops.stem_block_fwd(B, H, W, xb, wp, gamma.to(dev), beta.to(dev), rm, rv, training, scale, shift, mean, invstd, 0.1,
+                       dst, ld, 32, ws)
+    got = padded_to_nchw(dst, B, H // 2, W // 2, ld, cout, 32)
+    assert rel_l2(got, out.detach()) < TOL
+    assert halo_is_zero(dst, B, H // 2, W // 2, ld)
+    assert float(ops.padded_view(dst, B, H // 2, W // 2, ld)[..., :32].abs().max()) == 0.0      # the slice's neighbours
+    if not training:
+        assert torch.equal(rm.cpu(), rm0) and torch.equal(rv.cpu(), rv0)
+        return
+    assert torch.allclose(rm.cpu().double(), rm_ref, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(rv.cpu().double(), rv_ref, rtol=1e-4, atol=1e-5)
+    yd = y.detach()
+    assert torch.allclose(mean.cpu().double(), yd.mean((0, 2, 3)), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(invstd.cpu().double(), 1.0 / torch.sqrt(yd.var((0, 2, 3), unbiased=False) + 1e-5), rtol=1e-4)
+
+    gb = nchw_to_raw(gout * S, ld, 32)
+    dw = torch.full((cout, 3, 3, 3), float("nan"), device=dev)
+    dgamma, dbeta = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
+    ops.stem_block_bwd(B, H, W, xb, wp, gamma.to(dev), scale, shift, mean, invstd, 0.1, gb, ld, 32, dw, dgamma, dbeta, ws,
+                       mask=mask.to(dev) if masked else None, grad_scale=S)
+    gw = wl.grad * mask.double() if masked else wl.grad
+    print("stem block %dx%dx%d: out %.1e dW %.1e dgamma %.1e dbeta %.1e" % (
+        B, H, W, rel_l2(got, out.detach()), rel_l2(dw.cpu(), gw), rel_l2(dgamma.cpu(), gl.grad), rel_l2(dbeta.cpu(), bl.grad)))
+    assert rel_l2(dw.cpu(), gw) < TOL
+    assert rel_l2(dbeta.cpu(), bl.grad) < TOL
+    if masked:      # the dead filter's gamma gradient is exactly 0 in the reference (xhat = 0); elsewhere relative
+        assert float(dgamma[5].abs()) < 1e-6 * float(gl.grad.abs().max())
+        assert bool((dw.cpu()[mask == 0] == 0).all())
+    assert rel_l2(dgamma.cpu(), gl.grad) < TOL
+
+
 def _bn_ref(y, gamma, beta, slope, mode, training_stats=True):
     """fp32 reference of BN(train) -> leaky -> {plain, pool, reorg}; y is a leaf."""
     z = F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5)

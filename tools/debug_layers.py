@@ -1,5 +1,6 @@
 """Layer-by-layer comparison of the engine's buffers with the oracle (debug aid, GPU box)."""
 import os, sys
+os.environ.setdefault("MCAMD_STEM_FUSED", "0")   # this tool inspects the per-layer y / dY buffers of every block
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch

@@ -1,0 +1,77 @@
+"""Timing and statistics accuracy of the fused first block (csrc/conv_stem_block.hip) on the GPU box.
+
+    python tools/stem_block_bench.py [B]
+
+Prints HIP-event times of the forward (Gram + coefficients + fused pass) and backward calls at B x 416 x 416 for the
+tuning switches, and the relative error of the batch mean / invstd against float64 torch."""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import torch.nn.functional as F
+from modelcompression_amd import ops
+from util import to_padded, nchw_to_raw
+
+dev = torch.device("cuda")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+H = W = 416
+gen = torch.Generator().manual_seed(0)
+x = torch.rand(B, 3, H, W, generator=gen)
+w = torch.randn(32, 3, 3, 3, generator=gen) * 0.3
+gamma, beta = torch.rand(32, generator=gen) + 0.5, torch.randn(32, generator=gen) * 0.2
+xb, _ = to_padded(x.to(dev))
+g = ops.geom(B, H, W, 3, 3, 32, 4, 0, stem=1)
+wp, _ = ops.pack_weights(g, w.to(dev).contiguous())
+rm, rv = torch.zeros(32, device=dev), torch.ones(32, device=dev)
+scale, shift, mean, invstd = (torch.empty(32, device=dev) for _ in range(4))
+ws = torch.empty(ops.stem_block_workspace_bytes(), dtype=torch.uint8, device=dev)
+dst = ops.alloc_padded(B, H // 2, W // 2, 32, dev)
+gb = (torch.randn(B * (H // 2) * (W // 2), 32, generator=gen) * 4).half().to(dev).view(-1)
+dw = torch.empty(32, 3, 3, 3, device=dev)
+dg, db = torch.empty(32, device=dev), torch.empty(32, device=dev)
+
+
+def fwd():
+    ops.stem_block_fwd(B, H, W, xb, wp, gamma.to(dev), beta.to(dev), rm, rv, True, scale, shift, mean, invstd, 0.1, dst, 32, 0, ws)
+
+
+def bwd():
+    ops.stem_block_bwd(B, H, W, xb, wp, gamma.to(dev), scale, shift, mean, invstd, 0.1, gb, 32, 0, dw, dg, db, ws, grad_scale=4.0)
+
+
+def timeit(fn, n=20):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+# reference statistics in float64 on the GPU, in chunks of images
+wq = w.half().double().to(dev)
+s1 = torch.zeros(32, dtype=torch.float64, device=dev)
+s2 = torch.zeros(32, dtype=torch.float64, device=dev)
+for i in range(0, B, 4):
+    y = F.conv2d(x[i:i + 4].half().double().to(dev), wq, None, 1, 1)
+    s1 += y.sum((0, 2, 3))
+    s2 += (y * y).sum((0, 2, 3))
+M = B * H * W
+mref = s1 / M
+vref = s2 / M - mref * mref
+iref = 1.0 / torch.sqrt(vref + 1e-5)
+fwd()
+torch.cuda.synchronize()
+em = ((mean.double() - mref).abs() / mref.abs().clamp_min(1e-3)).max().item()
+ei = ((invstd.double() - iref).abs() / iref).max().item()
+print("batch statistics from the Gram matrix: max rel err mean %.2e invstd %.2e   (E[y^2]/var up to %.1f)" % (
+    em, ei, float((s2 / M / vref).max())))
+for un in ("1", "2", "4"):
+    os.environ["MCAMD_STEM_FWD_UN"] = un
+    print("B=%d fwd (gram + sums + coeffs + fused pass) UN=%s: %.1f us" % (B, un, timeit(fwd)))
+print("B=%d bwd (fused pass + sums + finish): %.1f us" % (B, timeit(bwd)))
