@@ -45,13 +45,14 @@ struct StemBlockArgs {
     float slope;
 };
 
-__device__ __forceinline__ float xor1(float v) {   // value of the neighbouring lane (lane ^ 1)
-    int i = __builtin_bit_cast(int, v);
-    i = __builtin_amdgcn_update_dpp(i, i, 0xB1, 0xF, 0xF, false);   // quad_perm [1, 0, 3, 2]
-    return __builtin_bit_cast(float, i);
-}
-
 __device__ __forceinline__ h4_t lo4(h8_t v) { return h4_t{v[0], v[1], v[2], v[3]}; }
+
+// A wave-uniform 64-bit element offset pinned to scalar registers: base pointer + this + a 32-bit lane byte offset
+// compiles to the scalar-base form of global_load (no 64-bit address arithmetic per lane).
+__device__ __forceinline__ long long uniform_off(long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
 
 // Position of a work unit (image b, unit row h, 32-column block w) in 32-bit arithmetic, stepped incrementally: a
 // 64-bit decode of the unit index per step cost more instructions than the step's MFMAs.
@@ -74,26 +75,26 @@ __device__ __forceinline__ void unit_advance(UnitPos& p, const UnitPos& d, int W
     p.b += d.b;
 }
 
-constexpr int XROW = 272;      // bytes of one staged window row: 34 pixels x 8 bytes
-constexpr int GD_BYTES = 2048; // one 32-pixel x 32-filter fp16 tile
+// Pitch of a staged window row (34 pixels x 8 bytes = 272 used).  384 = 96 banks: the four 16-lane groups of a
+// transposing read (row 0 | 1 at pitch distance, pixels +8 at 64 bytes) then touch disjoint bank ranges
+// (0-13, 32-45, 16-29, 48-61); at 272 bytes they overlapped and the reads of a step took longer than its MFMAs.
+constexpr int XROW = 384;
 
-// Window rows from the registers that feed the forward MFMAs into LDS, with channel 3 of every INTERIOR pixel set to
-// 1.0 (the NHWC4 image keeps 0 there): column (tap, 3) of the Gram matrix then holds the plain sums S.
-// Lane (pl, kg) holds pixels pl + 2 kg, pl + 2 kg + 1 of each row; lanes kg = 0 cover pixels 0-31, lane (30, 1) 32-33.
+// Window rows from the registers that feed the forward MFMAs into LDS; `ones`: channel 3 of every INTERIOR pixel is set
+// to 1.0 (the NHWC4 image keeps 0 there), so that column (tap, 3) of the Gram matrix holds the plain sums S.
+// Lane (pl, kg) holds pixels pl + 2 kg, pl + 2 kg + 1 of each row and writes the first of them: lanes kg = 0 cover pixels
+// 0-31, lanes (30, 1), (31, 1) pixels 32, 33, the other kg = 1 lanes repeat what lane (pl + 2, 0) writes (no branches).
 template <int NR>
 __device__ __forceinline__ void stage_window(char* win, const h8_t (&xr)[NR], int pl, int kg, int prow0, int pcol0, int H,
                                              int W, bool ones) {
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
-        h8_t v = xr[rr];
+        h4_t v = lo4(xr[rr]);
         if (ones) {
-            const bool rin = prow0 + rr >= 1 && prow0 + rr <= H;
             const int c0 = pcol0 + pl + 2 * kg;
-            v[3] = (rin && c0 >= 1 && c0 <= W) ? (half_t)1.f : (half_t)0.f;
-            v[7] = (rin && c0 + 1 >= 1 && c0 + 1 <= W) ? (half_t)1.f : (half_t)0.f;
+            v[3] = (prow0 + rr >= 1 && prow0 + rr <= H && c0 >= 1 && c0 <= W) ? (half_t)1.f : (half_t)0.f;
         }
-        if (kg == 0) *(h4_t*)(win + rr * XROW + pl * 8) = lo4(v);
-        else if (pl == 30) *(h8_t*)(win + rr * XROW + 32 * 8) = v;
+        *(h4_t*)(win + rr * XROW + (pl + 2 * kg) * 8) = v;
     }
 }
 
@@ -102,15 +103,16 @@ __device__ __forceinline__ void stage_window(char* win, const h8_t (&xr)[NR], in
 // goes to LDS and the MFMA fragments are gathered with the transposing read exactly as in wgrad_stem_kernel: F01 =
 // columns (ty in {0, 1}) x (tx, c), F2 = ty = 2.  C = F^T F: the SAME registers serve as the A and the B operand
 // (A[i][k] = F[k][i]).  Slab per workgroup: fp32 [48][48], slot = ty*16 + tx*4 + c (tx = 3 is a don't-care column).
-__global__ __launch_bounds__(512) void stem_gram_kernel(StemBlockArgs a) {
-    constexpr int PERW = 1024, NW = 8;
+__global__ __launch_bounds__(512, 4) void stem_gram_kernel(StemBlockArgs a) {     // 4 waves per SIMD = 2 workgroups per CU: <= 128 registers
+    constexpr int PERW = 3 * XROW + 128, NW = 8;     // two window buffers of PERW bytes per wave
     __shared__ __attribute__((aligned(16))) char smem[NW * 16 * 64 * 4];   // the final reduction needs 32 KB
+    static_assert(NW * 2 * PERW <= NW * 16 * 64 * 4, "window buffers");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 31, kg = lane >> 5;
-    char* my = smem + wave * PERW;
+    char* my = smem + wave * (2 * PERW);
     const unsigned my_addr = lds_addr_of(my);
-    if (lane < 52) *(int*)(my + 816 + lane * 4) = 0;        // bytes the fragment reads touch past the staged window
+    for (int i = lane; i < 2 * PERW / 4; i += 64) ((int*)my)[i] = 0;    // the fragment reads touch bytes past the staged pixels
     const int g4 = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
     const int krow = 8 * (g4 >> 1) + q;
     const unsigned b01 = my_addr + (g4 & 1) * XROW + (krow + p) * 8;
@@ -120,45 +122,56 @@ __global__ __launch_bounds__(512) void stem_gram_kernel(StemBlockArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) cbb[r] = cbc[r] = ccc[r] = 0.f;
 
-    // a wave takes batches of GD consecutive steps; all loads of a batch are in flight before its first window is staged
+    // A wave takes batches of GD consecutive steps: all image loads of a batch are in flight before its first window
+    // is staged, and inside a batch the windows alternate between two LDS buffers so that the LDS round trip of window
+    // d + 1 (write, transposing reads) runs under the MFMAs of window d.
     constexpr int GD = 4;
     const int nunits = (int)a.nunits;
     const int wstride = gridDim.x * NW * GD;
     int u0 = (blockIdx.x * NW + wave) * GD;
     UnitPos pos = unit_decode(u0 < nunits ? u0 : 0, a.Wb, a.H);
     const UnitPos dstep = unit_decode(wstride - (GD - 1), a.Wb, a.H), one = {0, 0, 1};
-    const int row_elems = (a.W + 2) * 4;
+    const unsigned row_elems = (a.W + 2) * 4, lane_off = (pl + 2 * kg) * 4;
+    auto reads = [&](int buf, Frag (&fb)[2], Frag (&fc)[2]) {
+        const unsigned o = buf * PERW;
+        fb[0].lo = tr_read4<0>(b01 + o), fb[0].hi = tr_read4<4 * 8>(b01 + o);
+        fc[0].lo = tr_read4<0>(b2 + o), fc[0].hi = tr_read4<4 * 8>(b2 + o);
+        fb[1].lo = tr_read4<16 * 8>(b01 + o), fb[1].hi = tr_read4<16 * 8 + 4 * 8>(b01 + o);
+        fc[1].lo = tr_read4<16 * 8>(b2 + o), fc[1].hi = tr_read4<16 * 8 + 4 * 8>(b2 + o);
+    };
     for (; u0 < nunits; u0 += wstride) {
         h8_t xr[GD][3];
         int uh[GD], uw[GD];
 #pragma unroll
         for (int d = 0; d < GD; ++d) {
             uh[d] = pos.h, uw[d] = pos.w;
-            const half_t* px = a.x + ((long long)(pos.b * (a.H + 2) + pos.h) * (a.W + 2) + pos.w * 32 + pl + 2 * kg) * 4;
+            // wave-uniform base (scalar registers) + a 32-bit lane offset
+            const half_t* xb = a.x + uniform_off(((long long)(pos.b * (a.H + 2) + pos.h) * (a.W + 2) + pos.w * 32) * 4);
             if (u0 + d < nunits) {
 #pragma unroll
-                for (int rr = 0; rr < 3; ++rr) xr[d][rr] = *(const h8_t*)(px + rr * row_elems);
+                for (int rr = 0; rr < 3; ++rr) xr[d][rr] = *(const h8_t*)((const char*)xb + (lane_off + rr * row_elems) * 2u);
             }
             if (d + 1 < GD) unit_advance(pos, one, a.Wb, a.H);
         }
         unit_advance(pos, dstep, a.Wb, a.H);
+        Frag fb[2][2], fc[2][2];
+        stage_window<3>(my, xr[0], pl, kg, uh[0], uw[0] * 32, a.H, a.W, true);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        reads(0, fb[0], fc[0]);
 #pragma unroll
         for (int d = 0; d < GD; ++d) {
             if (u0 + d < nunits) {          // wave-uniform
-                stage_window<3>(my, xr[d], pl, kg, uh[d], uw[d] * 32, a.H, a.W, true);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                Frag fb[2], fc[2];
-                fb[0].lo = tr_read4<0>(b01), fb[0].hi = tr_read4<4 * 8>(b01);
-                fc[0].lo = tr_read4<0>(b2), fc[0].hi = tr_read4<4 * 8>(b2);
-                fb[1].lo = tr_read4<16 * 8>(b01), fb[1].hi = tr_read4<16 * 8 + 4 * 8>(b01);
-                fc[1].lo = tr_read4<16 * 8>(b2), fc[1].hi = tr_read4<16 * 8 + 4 * 8>(b2);
-                lds_wait_all(fb[0]);
+                const bool more = d + 1 < GD && u0 + d + 1 < nunits;
+                if (more) stage_window<3>(my + ((d + 1) & 1) * PERW, xr[d + 1 < GD ? d + 1 : d], pl, kg, uh[d + 1 < GD ? d + 1 : d],
+                                          uw[d + 1 < GD ? d + 1 : d] * 32, a.H, a.W, true);
+                lds_wait_all(fb[d & 1][0]);     // the reads of window d (and the writes of window d + 1) have landed
+                if (more) reads((d + 1) & 1, fb[(d + 1) & 1], fc[(d + 1) & 1]);
 #pragma unroll
                 for (int k16 = 0; k16 < 2; ++k16) {
-                    tie(fb[k16]), tie(fc[k16]);
-                    cbb = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[k16].v(), fb[k16].v(), cbb, 0, 0, 0);
-                    cbc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[k16].v(), fc[k16].v(), cbc, 0, 0, 0);
-                    ccc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fc[k16].v(), fc[k16].v(), ccc, 0, 0, 0);
+                    tie(fb[d & 1][k16]), tie(fc[d & 1][k16]);
+                    cbb = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[d & 1][k16].v(), fb[d & 1][k16].v(), cbb, 0, 0, 0);
+                    cbc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[d & 1][k16].v(), fc[d & 1][k16].v(), cbc, 0, 0, 0);
+                    ccc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fc[d & 1][k16].v(), fc[d & 1][k16].v(), ccc, 0, 0, 0);
                 }
             }
         }
@@ -259,9 +272,15 @@ __global__ __launch_bounds__(1024) void stem_coeffs_kernel(const double* csum, c
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Forward: a unit = 32 columns x 2 rows of the conv output = 16 pooled pixels.  Y^T = W X^T as in stem_fwd_kernel
-// (accumulator lane = pixel, registers = channels), four image rows per unit feed both conv rows; the 2x2 window is
-// a register pair (rows) and a lane pair (columns).  LeakyReLU is monotonic, so it is applied to the window maximum.
+// Forward: a unit = 32 columns x 2 rows of the conv output = 16 pooled pixels.  Y = X W^T on v_mfma_f32_32x32x16_f16
+// with the image fragment as the A operand (row = pixel, the same 16-byte loads as stem_fwd_kernel) and the
+// register-resident weights as B: an accumulator's lane is a CHANNEL and its registers are pixels
+// (pixel = (r & 3) + 8 (r >> 2) + 4 kg), so a 2x2 pool window is four registers of one lane -- no cross-lane traffic,
+// one scale / shift pair per lane.  Four image rows per unit feed both conv rows.  LeakyReLU is monotonic, so it is
+// applied to the window maximum.  The 16 x 32 pooled tile is turned through 1 KB of LDS per wave and leaves as whole
+// 16-byte pieces (1 KB contiguous when dst_ld == 32).
+__device__ __forceinline__ int pooled_of(int q, int kg) { return (q & 1) + 4 * (q >> 1) + 2 * kg; }   // pooled pixel of register pair q
+
 template <int UN>
 __global__ __launch_bounds__(256) void stem_block_fwd_kernel(StemBlockArgs a) {
     __shared__ __attribute__((aligned(16))) half_t tile[4][16 * 32];
@@ -271,31 +290,24 @@ __global__ __launch_bounds__(256) void stem_block_fwd_kernel(StemBlockArgs a) {
     h8_t wf[3];
 #pragma unroll
     for (int ty = 0; ty < 3; ++ty) wf[ty] = *(const h8_t*)(a.w + (long long)pl * 96 + ty * 32 + 8 * kg);
-    float sc[16], sh[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int ch = (r & 3) + 8 * (r >> 2) + 4 * kg;
-        sc[r] = a.scale[ch];
-        sh[r] = a.shift[ch];
-    }
+    const float sc = a.scale[pl], sh = a.shift[pl];
     half_t* tw = tile[wave];
-    const bool odd = pl & 1;
     const int nunits = (int)a.nunits;
     const int wstride = gridDim.x * 4 * UN;
     int u0 = (blockIdx.x * 4 + wave) * UN;
     UnitPos pos = unit_decode(u0 < nunits ? u0 : 0, a.Wb, a.H2);
     const UnitPos dstep = unit_decode(wstride - (UN - 1), a.Wb, a.H2), one = {0, 0, 1};
-    const int row_elems = (a.W + 2) * 4;
+    const unsigned row_elems = (a.W + 2) * 4, lane_off = (pl + 2 * kg) * 4;
     for (; u0 < nunits; u0 += wstride) {
         h8_t xr[UN][4];
         int ub[UN], uh[UN], uw[UN];
 #pragma unroll
         for (int i = 0; i < UN; ++i) {
             ub[i] = pos.b, uh[i] = pos.h, uw[i] = pos.w;
-            const half_t* px = a.x + ((long long)(pos.b * (a.H + 2) + 2 * pos.h) * (a.W + 2) + pos.w * 32 + pl + 2 * kg) * 4;
+            const half_t* xb = a.x + uniform_off(((long long)(pos.b * (a.H + 2) + 2 * pos.h) * (a.W + 2) + pos.w * 32) * 4);
             if (u0 + i < nunits) {
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) xr[i][rr] = *(const h8_t*)(px + rr * row_elems);
+                for (int rr = 0; rr < 4; ++rr) xr[i][rr] = *(const h8_t*)((const char*)xb + (lane_off + rr * row_elems) * 2u);
             } else {
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) xr[i][rr] = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
@@ -310,26 +322,16 @@ __global__ __launch_bounds__(256) void stem_block_fwd_kernel(StemBlockArgs a) {
             for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
 #pragma unroll
             for (int ty = 0; ty < 3; ++ty) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ty], xr[i][ty], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ty], xr[i][ty + 1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xr[i][ty], wf[ty], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xr[i][ty + 1], wf[ty], acc1, 0, 0, 0);
             }
-            float av[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float z0 = __builtin_fmaf(acc0[r], sc[r], sh[r]), z1 = __builtin_fmaf(acc1[r], sc[r], sh[r]);
-                float m = fmaxf(z0, z1);
-                m = fmaxf(m, xor1(m));
+            for (int q = 0; q < 8; ++q) {
+                const float z00 = __builtin_fmaf(acc0[2 * q], sc, sh), z01 = __builtin_fmaf(acc0[2 * q + 1], sc, sh);
+                const float z10 = __builtin_fmaf(acc1[2 * q], sc, sh), z11 = __builtin_fmaf(acc1[2 * q + 1], sc, sh);
+                float m = fmaxf(fmaxf(z00, z01), fmaxf(z10, z11));
                 m = m > 0.f ? m : m * a.slope;
-                av[r] = fminf(fmaxf(m, -65504.f), 65504.f);
-            }
-            // both lanes of a column pair hold the pooled pixel pl >> 1: the even lane writes channel groups j = 0, 1,
-            // the odd lane j = 2, 3 (channels 8 j + 4 kg .. + 3)
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                h4_t v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (half_t)(odd ? av[8 + 4 * jj + e] : av[4 * jj + e]);
-                *(h4_t*)(tw + (pl >> 1) * 32 + 8 * ((odd ? 2 : 0) + jj) + 4 * kg) = v;
+                tw[pooled_of(q, kg) * 32 + pl] = (half_t)fminf(fmaxf(m, -65504.f), 65504.f);
             }
             const int prow = lane >> 2, pc = lane & 3;
             const h8_t v = *(const h8_t*)(tw + prow * 32 + pc * 8);
@@ -341,74 +343,72 @@ __global__ __launch_bounds__(256) void stem_block_fwd_kernel(StemBlockArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Backward: per unit recompute both conv rows, find the window argmax (first maximum in (h, w) scan order, torch's
-// max_pool2d rule), route G * leaky'(z) to it, and accumulate T = Gd^T V with the fragments of wgrad_stem_kernel:
-// the 32-pixel x 32-filter tiles Gd of the two rows are written to LDS from the registers, the window rows too.
+// Backward: per unit recompute both conv rows in the same orientation, find the window argmax (first maximum in
+// (h, w) scan order, torch's max_pool2d rule: row 0 wins a tie between the rows, column 0 inside a row), route
+// G * leaky'(z) to it, and accumulate T = Gd^T V.  Because a lane's registers are pixels of ONE channel, the routed
+// gradients are already the A operand of that product (row = channel, k = pixel (j & 3) + 8 (j >> 2) + 4 kg + 16 s):
+// they never touch LDS; the B operand is the image window, staged from the registers and gathered with the
+// transposing read as in wgrad_stem_kernel, with the row addresses following the same pixel order.
 // Slab per workgroup: fp32 [32][96] (T in the stem K layout) + [32] (dbeta).
-template <int A_OFF, int B_OFF>
-__device__ __forceinline__ void bwd_frags(unsigned a_addr, unsigned b01, unsigned b2, Frag& fa, Frag& fb, Frag& fc) {
-    fa.lo = tr_read4<A_OFF>(a_addr), fa.hi = tr_read4<A_OFF + 4 * 64>(a_addr);
-    fb.lo = tr_read4<B_OFF>(b01), fb.hi = tr_read4<B_OFF + 4 * 8>(b01);
-    fc.lo = tr_read4<B_OFF>(b2), fc.hi = tr_read4<B_OFF + 4 * 8>(b2);
+template <int OFF>
+__device__ __forceinline__ void win_frags(unsigned b01, unsigned b2, Frag& fb, Frag& fc) {
+    fb.lo = tr_read4<OFF>(b01), fb.hi = tr_read4<OFF + 8 * 8>(b01);
+    fc.lo = tr_read4<OFF>(b2), fc.hi = tr_read4<OFF + 8 * 8>(b2);
 }
 
 __global__ __launch_bounds__(512) void stem_block_bwd_kernel(StemBlockArgs a) {
-    constexpr int WIN = 1152, PERW = 2 * GD_BYTES + WIN, NW = 8;    // 5248 bytes per wave
-    __shared__ __attribute__((aligned(16))) char smem[NW * PERW];
-    static_assert(NW * PERW >= NW * 16 * 64 * 4, "reduction buffer");
+    constexpr int WIN = 4 * XROW + 128, NW = 8;
+    __shared__ __attribute__((aligned(16))) char smem[NW * 16 * 64 * 4];      // windows: NW x WIN bytes; reduction: 32 KB
+    static_assert(NW * WIN <= NW * 16 * 64 * 4, "window buffers");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 31, kg = lane >> 5;
-    char* my = smem + wave * PERW;
+    char* my = smem + wave * WIN;
     const unsigned my_addr = lds_addr_of(my);
-    if (lane < 16) *(int*)(my + 2 * GD_BYTES + 4 * XROW + lane * 4) = 0;
+    for (int i = lane; i < WIN / 4; i += 64) ((int*)my)[i] = 0;       // the fragment reads touch bytes past the staged pixels
     h8_t wf[3];
 #pragma unroll
     for (int ty = 0; ty < 3; ++ty) wf[ty] = *(const h8_t*)(a.w + (long long)pl * 96 + ty * 32 + 8 * kg);
-    float sc[16], sh[16], sb[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int ch = (r & 3) + 8 * (r >> 2) + 4 * kg;
-        sc[r] = a.scale[ch];
-        sh[r] = a.shift[ch];
-        sb[r] = 0.f;
-    }
+    const float sc = a.scale[pl], sh = a.shift[pl];
+    float sb = 0.f;
     f32x16_t t01, t2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) t01[r] = t2[r] = 0.f;
-    const int g4 = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-    const int krow = 8 * (g4 >> 1) + q;
-    const unsigned a_addr = my_addr + krow * 64 + (16 * (g4 & 1) + 4 * p) * 2;
-    const unsigned b01 = my_addr + 2 * GD_BYTES + (g4 & 1) * XROW + (krow + p) * 8;
-    const unsigned b2 = my_addr + 2 * GD_BYTES + 2 * XROW + (krow + p) * 8;
-    const bool odd = pl & 1;
+    // transposing reads: lane 4 qq + p of a 16-lane group supplies the address of k-row qq at tap column p; the k-rows
+    // of a half-wave are pixels 4 kg + qq (lo) and 8 + 4 kg + qq (hi), + 16 for the second half of the row
+    const int g4 = lane >> 4, qq = (lane & 15) >> 2, p = lane & 3;
+    const unsigned b01 = my_addr + (g4 & 1) * XROW + (4 * (g4 >> 1) + qq + p) * 8;
+    const unsigned b2 = my_addr + 2 * XROW + (4 * (g4 >> 1) + qq + p) * 8;
 
     // one unit per iteration; the image rows and G of the NEXT unit are loaded before the current one is processed
     const int nunits = (int)a.nunits;
     const int wstride = gridDim.x * NW;
-    const int row_elems = (a.W + 2) * 4;
+    const unsigned row_elems = (a.W + 2) * 4;
     h8_t xn[4];
-    h4_t gn[4];
+    half_t gn[8];
     int u = blockIdx.x * NW + wave;
     UnitPos pos = unit_decode(u < nunits ? u : 0, a.Wb, a.H2);
     const UnitPos dstep = unit_decode(wstride, a.Wb, a.H2);
-    auto fetch = [&]() {
-        const half_t* px = a.x + ((long long)(pos.b * (a.H + 2) + 2 * pos.h) * (a.W + 2) + pos.w * 32 + pl + 2 * kg) * 4;
+    const unsigned lane_off = (pl + 2 * kg) * 4;
+    unsigned goff[8];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) xn[rr] = *(const h8_t*)(px + rr * row_elems);
-        const half_t* gp = a.g + ((long long)(pos.b * a.H2 + pos.h) * a.W2 + pos.w * 16 + (pl >> 1)) * a.g_ld + a.g_choff + 4 * kg;
+    for (int q = 0; q < 8; ++q) goff[q] = (pooled_of(q, kg) * a.g_ld + a.g_choff + pl) * 2u;   // bytes
+    auto fetch = [&]() {     // wave-uniform bases (scalar registers) + 32-bit lane offsets
+        const half_t* xb = a.x + uniform_off(((long long)(pos.b * (a.H + 2) + 2 * pos.h) * (a.W + 2) + pos.w * 32) * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) gn[j] = *(const h4_t*)(gp + 8 * j);
+        for (int rr = 0; rr < 4; ++rr) xn[rr] = *(const h8_t*)((const char*)xb + (lane_off + rr * row_elems) * 2u);
+        const half_t* gb = a.g + uniform_off(((long long)(pos.b * a.H2 + pos.h) * a.W2 + pos.w * 16) * a.g_ld);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gn[q] = *(const half_t*)((const char*)gb + goff[q]);
     };
     if (u < nunits) fetch();
     for (; u < nunits; u += wstride) {
         h8_t xr[4];
-        h4_t gq[4];
+        half_t gq[8];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) xr[rr] = xn[rr];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) gq[j] = gn[j];
-        const int h2 = pos.h, wb = pos.w;
+        for (int q = 0; q < 8; ++q) gq[q] = gn[q];
         unit_advance(pos, dstep, a.Wb, a.H2);
         if (u + wstride < nunits) fetch();
 
@@ -417,46 +417,40 @@ __global__ __launch_bounds__(512) void stem_block_bwd_kernel(StemBlockArgs a) {
         for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
 #pragma unroll
         for (int ty = 0; ty < 3; ++ty) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ty], xr[ty], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ty], xr[ty + 1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xr[ty], wf[ty], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xr[ty + 1], wf[ty], acc1, 0, 0, 0);
         }
-        stage_window<4>(my + 2 * GD_BYTES, xr, pl, kg, 2 * h2, wb * 32, a.H, a.W, false);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            h4_t d0, d1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * j + e;
-                const float z0 = __builtin_fmaf(acc0[r], sc[r], sh[r]), z1 = __builtin_fmaf(acc1[r], sc[r], sh[r]);
-                const float o0 = xor1(z0), o1 = xor1(z1);
-                // the window in scan order: (row 0, col 0), (0, 1), (1, 0), (1, 1); this lane is column `odd`
-                const float v0 = odd ? o0 : z0, v1 = odd ? z0 : o0, v2 = odd ? o1 : z1, v3 = odd ? z1 : o1;
-                float best = v0;
-                int arg = 0;
-                if (v1 > best) best = v1, arg = 1;
-                if (v2 > best) best = v2, arg = 2;
-                if (v3 > best) best = v3, arg = 3;
-                const float gz = (float)gq[j][e] * (best > 0.f ? 1.f : a.slope);
-                const float e0 = arg == (odd ? 1 : 0) ? gz : 0.f, e1 = arg == (odd ? 3 : 2) ? gz : 0.f;
-                sb[r] += e0 + e1;
-                d0[e] = (half_t)e0;
-                d1[e] = (half_t)e1;
-            }
-            *(h4_t*)(my + pl * 64 + (8 * j + 4 * kg) * 2) = d0;
-            *(h4_t*)(my + GD_BYTES + pl * 64 + (8 * j + 4 * kg) * 2) = d1;
-        }
+        stage_window<4>(my, xr, pl, kg, 0, 0, a.H, a.W, false);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        Frag fa[4], fb[4], fc[4];
-        bwd_frags<0, 0>(a_addr, b01, b2, fa[0], fb[0], fc[0]);                                   // row 0, pixels 0-15
-        bwd_frags<16 * 64, 16 * 8>(a_addr, b01, b2, fa[1], fb[1], fc[1]);                        // row 0, pixels 16-31
-        bwd_frags<GD_BYTES, XROW>(a_addr, b01, b2, fa[2], fb[2], fc[2]);                         // row 1
-        bwd_frags<GD_BYTES + 16 * 64, XROW + 16 * 8>(a_addr, b01, b2, fa[3], fb[3], fc[3]);
-        lds_wait_all(fa[0]);
+        Frag fb[4], fc[4];
+        win_frags<0>(b01, b2, fb[0], fc[0]);                     // conv row 0, pixels 0-15
+        win_frags<16 * 8>(b01, b2, fb[1], fc[1]);                // conv row 0, pixels 16-31
+        win_frags<XROW>(b01, b2, fb[2], fc[2]);                  // conv row 1
+        win_frags<XROW + 16 * 8>(b01, b2, fb[3], fc[3]);
+        // the routed gradients: word q of a row = (pixel 2q | pixel 2q + 1) as fp16, only the winner non-zero
+        unsigned g0[8], g1[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float z00 = __builtin_fmaf(acc0[2 * q], sc, sh), z01 = __builtin_fmaf(acc0[2 * q + 1], sc, sh);
+            const float z10 = __builtin_fmaf(acc1[2 * q], sc, sh), z11 = __builtin_fmaf(acc1[2 * q + 1], sc, sh);
+            const float m0 = fmaxf(z00, z01), m1 = fmaxf(z10, z11);
+            const float best = fmaxf(m0, m1);
+            const float gz = (float)gq[q] * (best > 0.f ? 1.f : a.slope);
+            sb += gz;
+            const unsigned gh = (unsigned)__builtin_bit_cast(unsigned short, (half_t)gz);
+            const unsigned w0 = z00 >= z01 ? gh : gh << 16, w1 = z10 >= z11 ? gh : gh << 16;
+            g0[q] = m0 >= m1 ? w0 : 0u;
+            g1[q] = m0 >= m1 ? 0u : w1;
+        }
+        lds_wait_all(fb[0]);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            tie(fa[s]), tie(fb[s]), tie(fc[s]);
-            t01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s].v(), fb[s].v(), t01, 0, 0, 0);
-            t2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s].v(), fc[s].v(), t2, 0, 0, 0);
+            tie(fb[s]), tie(fc[s]);
+            const unsigned* gs = (s < 2 ? g0 : g1) + 4 * (s & 1);
+            union { unsigned u[4]; h8_t h; } fa;
+            fa.u[0] = gs[0], fa.u[1] = gs[1], fa.u[2] = gs[2], fa.u[3] = gs[3];
+            t01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.h, fb[s].v(), t01, 0, 0, 0);
+            t2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.h, fc[s].v(), t2, 0, 0, 0);
         }
     }
     __syncthreads();
@@ -478,19 +472,13 @@ __global__ __launch_bounds__(512) void stem_block_bwd_kernel(StemBlockArgs a) {
         }
         __syncthreads();
     }
-    // dbeta: lanes with the same kg hold the same channels
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float v = sb[r];
-#pragma unroll
-        for (int msk = 1; msk < 32; msk <<= 1) v += __shfl_xor(v, msk);
-        if (pl == 0) red[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg] = v;
-    }
+    // dbeta: lane (n, kg) summed G * leaky' over its pooled pixels of channel n
+    red[wave * 64 + lane] = sb;
     __syncthreads();
     if (tid < 32) {
         float v = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < NW; ++wv) v += red[wv * 32 + tid];
+        for (int wv = 0; wv < NW; ++wv) v += red[wv * 64 + tid] + red[wv * 64 + 32 + tid];
         out[3072 + tid] = v;
     }
     // columns the accumulators do not cover (tx slots 4-7 of every filter row) are never read
@@ -534,7 +522,7 @@ __global__ __launch_bounds__(1024) void stem_bwd_finish_kernel(const double* tsu
 struct Carve {      // workspace layout (bytes), all offsets multiples of 256
     size_t gram_slab, gram_sum, ctx, bwd_slab, bwd_sum, total;
 };
-constexpr int kGramWgs = 256, kBwdWgs = 256;   // one 8-wave workgroup per CU
+constexpr int kGramWgs = 512, kBwdWgs = 256;   // slab capacity; the launches use one 8-wave workgroup per CU
 Carve carve() {
     Carve c;
     size_t off = 0;
@@ -593,7 +581,9 @@ extern "C" int mcamd_stem_block_fwd(const mcamd_stem_block_desc* d, void* worksp
         g.nunits = (long long)d->B * d->H * g.Wb;
         g.slab = (float*)(ws + c.gram_slab);
         long long want = (g.nunits + 31) / 32;    // >= one batch of 4 steps per wave
-        const int grid = (int)(want < kGramWgs ? (want < 1 ? 1 : want) : kGramWgs);
+        const char* e_gw = getenv("MCAMD_STEM_GRAM_WGS");     // tuning switch (<= kGramWgs)
+        const int gmax = e_gw && atoi(e_gw) > 0 && atoi(e_gw) <= kGramWgs ? atoi(e_gw) : 512;   // 2 workgroups per CU: 223 vs 239 us
+        const int grid = (int)(want < gmax ? (want < 1 ? 1 : want) : gmax);
         hipLaunchKernelGGL(stem_gram_kernel, dim3(grid), dim3(512), 0, st, g);
         MCAMD_LAUNCH_CHECK("stem_gram");
         hipLaunchKernelGGL(slab_sum_kernel, dim3(2304 / 16), dim3(256), 0, st, (const float*)g.slab, grid, 2304,
@@ -609,7 +599,7 @@ extern "C" int mcamd_stem_block_fwd(const mcamd_stem_block_desc* d, void* worksp
     long long want = (a.nunits + 7) / 8;          // >= one pass of 2 units per wave
     const int grid = (int)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
     const char* e_un = getenv("MCAMD_STEM_FWD_UN");   // tuning switch
-    const int un = e_un ? atoi(e_un) : 2;
+    const int un = e_un ? atoi(e_un) : 4;
     if (un == 4) hipLaunchKernelGGL(stem_block_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, a);
     else if (un == 1) hipLaunchKernelGGL(stem_block_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(stem_block_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, a);
