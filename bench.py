@@ -305,7 +305,7 @@ def main():
         else:
             perc = 40.0 if args.workload == "filter40" else 60.0
             masks, wl_name = quick_filter_prune(model, perc), "filter-pruned %g %% (kept filters only)" % perc
-        if world > 1:
+        if world > 1 or (dp.rehearsal() and dist.is_initialized()):
             dp.broadcast_masks(masks, src=0)
         model.set_masks(masks)
     if args.workload == "slim60":
@@ -314,7 +314,8 @@ def main():
     sgd_kw = {"fused": True} if os.environ.get("MCAMD_SGD_FUSED", "1") == "1" else {}
     opt = torch.optim.SGD(model.parameters(), lr=1e-5, momentum=0.9, dampening=0, weight_decay=0.0005 * B, **sgd_kw)
     reducer = None
-    if world > 1:
+    dp_on = world > 1 or (dp.rehearsal() and dist.is_initialized())     # MCAMD_DP_REHEARSE=1: one-rank RCCL rehearsal
+    if dp_on:
         # static weight masks (configs[3]): only the kept gradient entries travel
         reducer = dp.attach(model, dp.GradReducer(transport=args.transport),
                             masks=masks if args.workload == "weight80" else None)
@@ -331,7 +332,7 @@ def main():
         opt.step()
 
     def fence():
-        if world > 1:
+        if dp_on:
             dist.barrier(device_ids=[local]) if dist.get_backend() == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
@@ -340,7 +341,7 @@ def main():
     for it in range(10):
         step()
         over = model.grad_overflowed()
-        if world > 1:
+        if dp_on:
             over = not dp.all_ranks_ok(not over, dev)
         if not over:
             break
@@ -356,7 +357,7 @@ def main():
     flat = model._last_flat_grad
     assert flat is not None and bool(torch.isfinite(flat).all()), "non-finite gradients in the timed run"
     assert not model.grad_overflowed(), "a scaled gradient saturated the fp16 range in the timed run"
-    if world > 1:
+    if dp_on:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -455,7 +456,7 @@ def main():
                      "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4),
                      "measured": "HIP events around every launch in %d extra steps after the timed region" % nprof},
     }
-    if world > 1:
+    if dp_on:
         res["cpu_baseline"] = None
         res["collective"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                              "transport": reducer.transport, "kept_fraction": round(reducer.kept_fraction, 4),
@@ -467,4 +468,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        try:
+            import torch.distributed as _d
+            if _d.is_available() and _d.is_initialized():
+                _d.destroy_process_group()
+        except Exception:
+            pass

@@ -189,6 +189,16 @@ int mcamd_bn_coeffs(const float* stats, int32_t stats_rows, int32_t stats_ld, in
                     float* scale, float* shift, float* save_mean, float* save_invstd,
                     const int32_t* chan_perm, void* stream);
 
+/* As mcamd_bn_coeffs; `ones_channel` >= 0 names ONE physical channel whose coefficients are forced to scale 0 /
+ * shift 1 after the statistics update: the BatchNorm + LeakyReLU pass then writes 1.0 at every interior pixel of that
+ * channel (0 stays in the halo).  The engine uses the first dead channel behind the kept filters of a filter-pruned
+ * layer this way when the consumer folds the dead inputs (mcamd_fold_weights); -1 = none. */
+int mcamd_bn_coeffs_ex(const float* stats, int32_t stats_rows, int32_t stats_ld, int32_t C, int64_t count,
+                       const float* gamma, const float* beta, float* running_mean, float* running_var,
+                       float momentum, float eps, int32_t training,
+                       float* scale, float* shift, float* save_mean, float* save_invstd,
+                       const int32_t* chan_perm, int32_t ones_channel, void* stream);
+
 #define MCAMD_DST_PLAIN 0  /* same resolution */
 #define MCAMD_DST_POOL 1   /* 2x2/2 max pool */
 #define MCAMD_DST_REORG 2  /* reorg stride 2: out channel = (hs*2+ws)*C + c at (h/2, w/2) */
@@ -240,9 +250,42 @@ typedef struct mcamd_act_bwd_desc {
                                   as the split-storage forward keeps them) */
     int32_t* overflow;         /* optional device flag, set to 1 when a dY value was clamped to +-65504 (see
                                   mcamd_conv_epilogue.overflow) */
+    int32_t skip_dead_param_grads; /* n > 0: dgamma / dbeta of the physical channels c >= n are NOT written -- the
+                                  consumer that folded those dead channels delivers their gradients
+                                  (mcamd_unfold_wgrad) and `g` holds nothing for them; 0 = write all */
 } mcamd_act_bwd_desc;
 size_t mcamd_bn_act_bwd_workspace_bytes(const mcamd_act_bwd_desc* d);
 int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Dead INPUT channels of a filter-pruned network (csrc/fold.hip).  A fully pruned filter
+ * feeds its consumer the constant leaky(beta) (0 in the halo); all such channels together
+ * act like ONE channel of ones convolved with the folded filter sum_c leaky(beta_c) W[n][c].
+ * The engine runs the consumer's forward / dgrad / wgrad on the producer's kept channels + that
+ * one channel with the augmented weights built by mcamd_fold_weights, and maps the augmented
+ * weight gradient back with mcamd_unfold_wgrad (which also yields dbeta of the producer's dead
+ * channels).  Exact on the reference's semantics: F.conv2d(x, weight * mask) at layers.py:59-64
+ * and the BatchNorm / LeakyReLU / MaxPool of nets.py:798-821 between the two convolutions.
+ *   w, mask : the consumer's OIHW fp32 master [cout_t][cin_t][k][k] and mask (or NULL)
+ *   rows    : device int32[n] physical filter -> tensor row (NULL = identity; n = filters computed)
+ *   cols    : device int32[cin_t] physical input channel -> tensor column, kept channels first
+ *             (NULL = identity); the first cin_k are taken as they are, the rest are folded
+ *   beta    : the PRODUCER's BatchNorm bias in the module's channel order, fp32[cin_t]
+ *   waug / dwaug : fp32 [n][cin_aug][k][k], cin_aug >= cin_k + 1 (the convolution kernels want a channel count
+ *             that is a multiple of 8): column cin_k is the folded filter, the columns behind it are zero
+ * ------------------------------------------------------------------------- */
+typedef struct mcamd_fold_desc {
+    const float* w; const float* mask;
+    const int32_t* rows; const int32_t* cols;
+    const float* beta; float slope;
+    int32_t n, cin_t, cin_k, cin_aug, ksize;
+} mcamd_fold_desc;
+int mcamd_fold_weights(const mcamd_fold_desc* d, float* waug, void* stream);
+/* dw_oihw rows outside rows[] are not written (the caller zeroes them).  prod_dbeta / prod_dgamma: the producer's
+ * gradient vectors in the module's order; dead channels receive dbeta (`accumulate` != 0: added to what an earlier
+ * consumer of the same producer wrote) and dgamma = 0. */
+int mcamd_unfold_wgrad(const mcamd_fold_desc* d, const float* dwaug, float* dw_oihw, float* prod_dbeta,
+                       float* prod_dgamma, int32_t accumulate, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * The first block as ONE unit: conv1 (3 -> 32 filters, 3x3) + BatchNorm2d + LeakyReLU

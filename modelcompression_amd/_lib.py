@@ -58,7 +58,13 @@ class ActBwdDesc(C.Structure):
                 ("dy", C.c_void_p), ("dy_ld", C.c_int32), ("dy_choff", C.c_int32),
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("grad_scale", C.c_float),
                 ("dy_keep", C.c_void_p), ("chan_perm", C.c_void_p), ("y_dtype", C.c_int32),
-                ("overflow", C.c_void_p)]
+                ("overflow", C.c_void_p), ("skip_dead_param_grads", C.c_int32)]
+
+
+class FoldDesc(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("mask", C.c_void_p), ("rows", C.c_void_p), ("cols", C.c_void_p),
+                ("beta", C.c_void_p), ("slope", C.c_float),
+                ("n", C.c_int32), ("cin_t", C.c_int32), ("cin_k", C.c_int32), ("cin_aug", C.c_int32), ("ksize", C.c_int32)]
 
 
 class StemBlockDesc(C.Structure):
@@ -95,6 +101,9 @@ SIGNATURES = {
     "mcamd_conv_wgrad_workspace_bytes": (_SZ, [C.POINTER(ConvGeom)]),
     "mcamd_conv_wgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _P, _I32, _I32, _P, C.POINTER(ChanMap), _F, _P, _P, _P, _SZ, _P]),
     "mcamd_bn_coeffs": (C.c_int, [_P, _I32, _I32, _I32, _I64, _P, _P, _P, _P, _F, _F, _I32, _P, _P, _P, _P, _P, _P]),
+    "mcamd_bn_coeffs_ex": (C.c_int, [_P, _I32, _I32, _I32, _I64, _P, _P, _P, _P, _F, _F, _I32, _P, _P, _P, _P, _P, _I32, _P]),
+    "mcamd_fold_weights": (C.c_int, [C.POINTER(FoldDesc), _P, _P]),
+    "mcamd_unfold_wgrad": (C.c_int, [C.POINTER(FoldDesc), _P, _P, _P, _P, _I32, _P]),
     "mcamd_bn_act_fwd": (C.c_int, [C.POINTER(ActDesc), _P]),
     "mcamd_bn_act_bwd_workspace_bytes": (_SZ, [C.POINTER(ActBwdDesc)]),
     "mcamd_bn_act_bwd": (C.c_int, [C.POINTER(ActBwdDesc), _P, _SZ, _P]),

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(1024) void bn_coeffs_kernel(const float* stats, int
                                                          const float* gamma, const float* beta, float* rmean,
                                                          float* rvar, float momentum, float eps, int training,
                                                          float* scale, float* shift, float* save_mean,
-                                                         float* save_invstd, const int* perm) {
+                                                         float* save_invstd, const int* perm, int ones_channel) {
     __shared__ double red[2][16][RED_CPB];
     const int cx = threadIdx.x & (RED_CPB - 1), ry = threadIdx.x / RED_CPB;
     const int c = blockIdx.x * RED_CPB + cx;
@@ -82,6 +82,7 @@ __global__ __launch_bounds__(1024) void bn_coeffs_kernel(const float* stats, int
     float sc = (float)((double)gamma[pc] * invstd);
     scale[c] = sc;
     shift[c] = (float)((double)beta[pc] - mean * (double)sc);
+    if (c == ones_channel) scale[c] = 0.f, shift[c] = 1.f;      // the activation pass writes ones here (fold.hip)
     if (save_mean) save_mean[c] = (float)mean;
     if (save_invstd) save_invstd[c] = (float)invstd;
 }
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(ActBwdArgs a) {
 
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* slab, int nblocks, int C, double count,
                                                                float inv_scale, float* dgamma, float* dbeta,
-                                                               float* coef, const int* perm) {
+                                                               float* coef, const int* perm, int skip_from) {
     __shared__ double red[2][16][RED_CPB];
     const int cx = threadIdx.x & (RED_CPB - 1), ry = threadIdx.x / RED_CPB;
     const int c = blockIdx.x * RED_CPB + cx;
@@ -410,8 +411,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* slab
     block_reduce2(sb, sg, red);
     if (ry != 0 || c >= C) return;
     const int pc = perm ? perm[c] : c;   // parameter-order index of this physical channel
-    if (dbeta) dbeta[pc] = (float)(sb * inv_scale);
-    if (dgamma) dgamma[pc] = (float)(sg * inv_scale);
+    const bool skip = skip_from > 0 && c >= skip_from;   // a folded dead channel: its consumer delivers these gradients (fold.hip)
+    if (dbeta && !skip) dbeta[pc] = (float)(sb * inv_scale);
+    if (dgamma && !skip) dgamma[pc] = (float)(sg * inv_scale);
     coef[c] = (float)(sb / count);
     coef[C + c] = (float)(sg / count);
 }
@@ -464,17 +466,27 @@ static int stream_grid(long long items) {
     return (int)g;
 }
 
+extern "C" int mcamd_bn_coeffs_ex(const float* stats, int32_t stats_rows, int32_t stats_ld, int32_t C, int64_t count,
+                                  const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                  float momentum, float eps, int32_t training, float* scale, float* shift,
+                                  float* save_mean, float* save_invstd, const int32_t* chan_perm, int32_t ones_channel,
+                                  void* stream) {
+    MCAMD_REQUIRE(C > 0 && gamma && beta && running_mean && running_var && scale && shift, "bn_coeffs: null argument");
+    MCAMD_REQUIRE(!training || (stats && stats_rows > 0 && stats_ld >= C && count > 0), "bn_coeffs: bad statistics slab");
+    MCAMD_REQUIRE(ones_channel < C, "bn_coeffs: ones_channel %d outside the %d channels", ones_channel, C);
+    hipLaunchKernelGGL(bn_coeffs_kernel, dim3((C + RED_CPB - 1) / RED_CPB), dim3(1024), 0, (hipStream_t)stream, stats, stats_rows,
+                       stats_ld, C, (double)count, gamma, beta, running_mean, running_var, momentum, eps, training,
+                       scale, shift, save_mean, save_invstd, (const int*)chan_perm, ones_channel < 0 ? -1 : ones_channel);
+    MCAMD_LAUNCH_CHECK("bn_coeffs");
+    return MCAMD_OK;
+}
+
 extern "C" int mcamd_bn_coeffs(const float* stats, int32_t stats_rows, int32_t stats_ld, int32_t C, int64_t count,
                                const float* gamma, const float* beta, float* running_mean, float* running_var,
                                float momentum, float eps, int32_t training, float* scale, float* shift,
                                float* save_mean, float* save_invstd, const int32_t* chan_perm, void* stream) {
-    MCAMD_REQUIRE(C > 0 && gamma && beta && running_mean && running_var && scale && shift, "bn_coeffs: null argument");
-    MCAMD_REQUIRE(!training || (stats && stats_rows > 0 && stats_ld >= C && count > 0), "bn_coeffs: bad statistics slab");
-    hipLaunchKernelGGL(bn_coeffs_kernel, dim3((C + RED_CPB - 1) / RED_CPB), dim3(1024), 0, (hipStream_t)stream, stats, stats_rows,
-                       stats_ld, C, (double)count, gamma, beta, running_mean, running_var, momentum, eps, training,
-                       scale, shift, save_mean, save_invstd, (const int*)chan_perm);
-    MCAMD_LAUNCH_CHECK("bn_coeffs");
-    return MCAMD_OK;
+    return mcamd_bn_coeffs_ex(stats, stats_rows, stats_ld, C, count, gamma, beta, running_mean, running_var, momentum, eps,
+                              training, scale, shift, save_mean, save_invstd, chan_perm, -1, stream);
 }
 
 static int check_c(int C, const char* what) {
@@ -608,7 +620,8 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
     BWD_LAUNCH(0)
     MCAMD_LAUNCH_CHECK("bn_act_bwd reduce");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + RED_CPB - 1) / RED_CPB), dim3(1024), 0, st, (const float*)a.slab, grid, d->C,
-                       count, 1.0f / d->grad_scale, d->dgamma, d->dbeta, coef, (const int*)d->chan_perm);
+                       count, 1.0f / d->grad_scale, d->dgamma, d->dbeta, coef, (const int*)d->chan_perm,
+                       d->skip_dead_param_grads);
     MCAMD_LAUNCH_CHECK("bn_act_bwd finalize");
     BWD_LAUNCH(1)
     MCAMD_LAUNCH_CHECK("bn_act_bwd apply");

@@ -31,6 +31,12 @@ import torch
 import torch.distributed as dist
 
 
+def rehearsal():
+    """MCAMD_DP_REHEARSE=1: run the data-parallel machinery (process group, bucketed collectives, barriers) with
+    however many ranks there are -- including one."""
+    return os.environ.get("MCAMD_DP_REHEARSE", "0") == "1"
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).
     The rank's GPU is selected BEFORE the process group is created and handed to it as
@@ -42,8 +48,19 @@ def init_from_env(backend=None):
     if dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    if world == 1 and not rehearsal():
         return 0, 1
+    if world == 1:
+        # MCAMD_DP_REHEARSE=1: a ONE-rank process group, so that a 1-GPU box still executes every RCCL call of the
+        # N > 1 path (communicator creation bound to the device, asynchronous all-reduces on the side stream, barriers)
+        import socket
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if "MASTER_PORT" not in os.environ:
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+            s.close()
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -67,6 +84,7 @@ class GradReducer:
 
     def __init__(self, world_size=None, chunk_elems=64 << 20, bucket_elems=8 << 20, transport=None, fp16_scale=256.0):
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.active = self.world > 1 or (rehearsal() and dist.is_initialized())
         self.chunk = int(chunk_elems)
         self.bucket = int(bucket_elems)
         self.transport = transport or os.environ.get("MCAMD_DP_TRANSPORT", "fp32")
@@ -158,7 +176,7 @@ class GradReducer:
         """`flat[lo:hi]` is final (all kernels that write it are enqueued on the current stream).
         Slices arrive in descending, contiguous order; a collective is launched whenever the
         accumulated slice reaches `bucket_elems` (of travelling elements)."""
-        if self.world == 1:
+        if not self.active:
             return
         if self._hi is None:
             self._lo, self._hi = lo, hi
@@ -182,7 +200,7 @@ class GradReducer:
 
     def finish(self, flat):
         """End of backward: send what is left, wait for every collective, average."""
-        if self.world == 1:
+        if not self.active:
             return flat
         if self._hi is None:                      # nothing was reported piecewise: whole buffer at once
             self._lo, self._hi = 0, flat.numel()
@@ -199,14 +217,14 @@ class GradReducer:
         return flat
 
     def reduce_flat(self, flat):
-        if self.world == 1:
+        if not self.active:
             return flat
         self._lo = self._hi = None
         return self.finish(flat)
 
     def reduce_params(self, params):
         grads = [p.grad for p in params if p.grad is not None]
-        if self.world == 1 or not grads:
+        if not self.active or not grads:
             return
         flat = torch.cat([g.reshape(-1) for g in grads])
         kept, self._kept = self._kept, None      # separate gradient tensors: dense transport
@@ -233,7 +251,7 @@ def attach(model, reducer=None, masks=None):
 
 def broadcast_masks(masks, src=0):
     """Rank `src` computed the masks (ranking stays single-GPU); everyone else receives them."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and (dist.get_world_size() > 1 or rehearsal()):
         for m in masks:
             dist.broadcast(m, src=src)
     return masks
@@ -268,7 +286,7 @@ def sync_buffers(model):
 def all_ranks_ok(ok, device=None):
     """Collective AND of a per-rank condition (e.g. "my loss and gradients are finite"), so that every rank takes
     the same branch -- a rank that raised alone would leave its peers blocked in the next all-reduce."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not (dist.is_initialized() and (dist.get_world_size() > 1 or rehearsal())):
         return bool(ok)
     t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if dist.get_backend() == "nccl" else None)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)

@@ -255,6 +255,14 @@ class Engine:
         for s, ls in by_src.items():
             if len(ls) > 1:
                 raise NotImplementedError("tensor %d feeds %d conv blocks; one consumer conv per tensor is supported" % (s, len(ls)))
+        # which conv block produces a tensor id (its pooled / reorged / plain output and the full-resolution copy)
+        self.producer_of = {}
+        for lay in self.layers:
+            if not lay.is_last:
+                self.producer_of[lay.out_id] = lay
+                if lay.out2_id is not None:
+                    self.producer_of[lay.out2_id] = lay
+            lay.fold, lay.ones_idx, lay.skip_dead, lay.fold_consumers, lay.bn_narrow = None, -1, False, [], False
         # a concat tensor's members are consumed through the concat's consumer
         self.consumer_of = {}
         for lay in self.layers:
@@ -362,7 +370,7 @@ class Engine:
     def conv_flops(self, lay):
         """Algorithmic FLOPs of one forward conv launch (2 * M * Cout * Cin * k*k, unpadded); with filter
         compaction Cout is the number of filters the launch actually computes."""
-        return 2.0 * lay.M * lay.n_act * lay.cin * lay.k * lay.k
+        return 2.0 * lay.M * lay.n_act * (lay.fold_aug if lay.fold is not None else lay.cin) * lay.k * lay.k
 
     # ------------------------------------------------------------------ weights
     def _signature(self):
@@ -373,9 +381,12 @@ class Engine:
             sig.append((w.data_ptr(), w._version, None if m is None else (m.data_ptr(), m._version)))
         return tuple(sig)
 
-    def pack(self, force=False):
+    def pack(self, force=False, training=True):
         """fp32 master * mask -> fp16 kernel layouts (replaces layers.py:59's per-forward multiply)."""
         sig = self._signature()
+        if any(lay.fold is not None for lay in self.layers) and training != getattr(self, "_training", None):
+            force = True          # the folded constants differ between batch and running statistics
+        self._training = training
         if not force and sig == self._packed_sig and not self.model._weights_dirty:
             return
         mkeys = tuple(None if not lay.conv.mask_flag else (lay.conv.mask.data_ptr(), lay.conv.mask._version)
@@ -407,6 +418,10 @@ class Engine:
                 if lay.stem:
                     continue
                 self._pack_keep += [w, mask]
+                if lay.fold is not None:     # augmented weights (kept inputs + the folded ones-channel), rebuilt per step
+                    jobs.append(dict(w=lay.waug, mask=None, rows=None, cols=None, cout=lay.n_act, cin=lay.fold_aug,
+                                     ksize=lay.k, dst_fwd=lay.wp, dst_dgrad=lay.wd))
+                    continue
                 jobs.append(dict(w=w, mask=mask, rows=lay.g_rows, cols=lay.g_cols, cout=lay.n_act, cin=lay.cin, ksize=lay.k,
                                  dst_fwd=lay.wp, dst_dgrad=lay.wd))
             self._pack_table = ops.pack_table(jobs, self.device) if jobs else None
@@ -415,6 +430,11 @@ class Engine:
             if lay.stem:
                 mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
                 ops.pack_weights(lay.geom_act, lay.conv.weight.data, mask, True, False, lay.wp, None, rows=lay.g_rows)
+        for lay in self.layers:
+            if lay.fold is not None:
+                mask = lay.conv.mask if lay.conv.mask_flag else None
+                ops.fold_weights(lay.conv.weight.data, mask, lay.g_rows, lay.g_cols, self._fold_constants(lay.fold, self._training),
+                                 lay.fold.slope, lay.n_act, lay.fold_cin, lay.waug)
         if self._pack_table is not None:
             ops.pack_many(*self._pack_table)
         self._packed_sig = sig
@@ -518,8 +538,74 @@ class Engine:
                 tperm[ind] = tperm[src[0]]
             else:
                 tperm[ind] = None
+        wbytes = max(wbytes, self._plan_folds())
         if wbytes > self.wgrad_ws.numel():
             self.wgrad_ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+
+    def _plan_folds(self):
+        """Dead INPUT channels (csrc/fold.hip).  A compacted producer whose every consumer reads its tensor directly (not
+        through a concat or reorg) turns its first dead physical channel into a channel of ones (mcamd_bn_coeffs_ex) and
+        each consumer runs forward / dgrad / wgrad on  kept + 1  input channels with augmented weights: the dead
+        channels' constants leaky(beta) are folded into the filter of the ones-channel, exactly, borders included.
+        Returns the weight-gradient workspace bytes the new geometries need."""
+        dev = self.device
+        for lay in self.layers:
+            lay.fold, lay.ones_idx, lay.skip_dead, lay.fold_consumers, lay.bn_narrow = None, -1, False, [], False
+            lay.waug = lay.dwaug = None
+            if lay.gin is not None:
+                lay.gin.zero_()       # a folding consumer's dgrad leaves the dead channels of G untouched: they must be finite
+        if not (self.compact and os.environ.get("MCAMD_FOLD_DEAD", "1") == "1"):
+            return 16
+        wbytes = 16
+        for prod in self.layers:
+            if prod.perm is None or prod.is_last or prod.mode == L.DST_REORG or prod.n_act >= prod.cout:
+                continue
+            outs = [t for t in (prod.out_id, prod.out2_id) if t is not None and t in self.consumer_of]
+            cons = [self.consumer_of[t] for t in outs]
+            if not cons or any(c.src != t or c.stem or c.tin.choff != 0 for c, t in zip(cons, outs)):
+                continue              # a concat member / reorg source: its consumer reads every channel
+            # the augmented channel count keeps the kernels' fast shapes (whole 64-channel K blocks for wide inputs), and
+            # folding must remove at least a quarter of the input channels to pay for its ragged tiles (measured on
+            # conv19 of the 40 % model, 840 of 1024 channels: dgrad 0.188 -> 0.294 ms)
+            aug = ops.round_up(prod.n_act + 1, 64 if prod.cout >= 256 else 8)
+            if aug > 0.75 * prod.cout:
+                continue
+            prod.ones_idx, prod.skip_dead = prod.n_act, True
+            prod.fold_consumers = sorted(cons, key=lambda c: -c.li)      # backward order: the first one initialises dbeta
+            # BatchNorm / activation passes on the kept channels only (their kernels keep one 8-channel group per thread:
+            # 8 x a power of two channels); the ones-channel is then written once, here, instead of by every forward pass
+            ch = prod.n_act // 8
+            prod.bn_narrow = prod.n_act % 8 == 0 and ch >= 1 and (ch & (ch - 1)) == 0 and ch <= 256 and \
+                os.environ.get("MCAMD_BN_NARROW", "1") == "1"
+            if prod.bn_narrow:
+                for t in (prod.out_t, prod.out2_t):
+                    if t is not None:
+                        v = ops.padded_view(self.bufs[t.buf], self.B, t.H, t.W, t.ld)[:, 1:-1, 1:-1]
+                        v[..., t.choff + prod.n_act + 1:t.choff + prod.cout] = 0
+                        v[..., t.choff + prod.n_act] = 1
+                prod.dy.zero_()
+            for c in cons:
+                c.fold = prod
+                c.fold_cin = prod.n_act
+                c.fold_aug = min(aug, ops.round_up(prod.cout, 8))      # padding columns: zero weights
+                c.geom_act = ops.geom(self.B, c.H, c.W, c.k, c.fold_aug, c.n_act, c.tin.ld, c.tin.choff, 0)
+                c.gather = True
+                c.waug = torch.zeros(c.n_act, c.fold_aug, c.k, c.k, dtype=torch.float32, device=dev)
+                c.dwaug = torch.zeros_like(c.waug)
+                if c.bn is not None:
+                    rows = ops.stats_rows(c.geom_act)
+                    if c.stats.shape[0] != rows:
+                        c.stats = torch.zeros(rows, 2, c.stats.shape[2], dtype=torch.float32, device=dev)
+                wbytes = max(wbytes, ops.wgrad_workspace_bytes(c.geom_act))
+        return wbytes
+
+    def _fold_constants(self, prod, training):
+        """Pre-activation value of the producer's dead channels in the module's channel order: y = 0 there, so
+        z = shift = beta in training (batch mean 0) and beta - running_mean * gamma / sqrt(running_var + eps) in eval."""
+        bn = prod.bn
+        if training:
+            return bn.bias.data
+        return bn.bias.data - bn.running_mean * bn.weight.data / torch.sqrt(bn.running_var + bn.eps)
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, training):
@@ -533,7 +619,7 @@ class Engine:
                 if not lay.train_ok:
                     raise McamdError("conv block %d: training needs a BN channel count of 8 * (power of two), got %d"
                                      % (lay.index, lay.cout))
-        self.pack(force=training)
+        self.pack(force=training, training=training)
         self.serial += 1
         tin = self.layers[0].tin
         xs = x.detach().contiguous().float()
@@ -591,10 +677,11 @@ class Engine:
             self._timed('fwd', lay, ops.conv_fwd_raw, lay.geom_act, xin, lay.wp, lay.y, lay.cout, 0, lay.stats if training else None)
             ops.bn_coeffs(lay.stats if training else None, lay.cout, lay.M, bn.weight.data, bn.bias.data,
                           bn.running_mean, bn.running_var, training, lay.scale, lay.shift, lay.mean, lay.invstd,
-                          momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps, perm=lay.perm32)
+                          momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps, perm=lay.perm32,
+                          ones_channel=lay.ones_idx)
             t, t2 = lay.out_t, lay.out2_t
-            ops.bn_act_fwd(B, lay.H, lay.W, lay.cout, lay.y, lay.cout, 0, lay.scale, lay.shift, lay.slope, lay.mode,
-                           self.bufs[t.buf], t.ld, t.choff,
+            ops.bn_act_fwd(B, lay.H, lay.W, lay.n_act if lay.bn_narrow else lay.cout, lay.y, lay.cout, 0, lay.scale, lay.shift,
+                           lay.slope, lay.mode, self.bufs[t.buf], t.ld, t.choff,
                            self.bufs[t2.buf] if t2 is not None else None,
                            t2.ld if t2 is not None else 0, t2.choff if t2 is not None else 0, border=lay.border)
         if training:
@@ -654,32 +741,49 @@ class Engine:
                 if lay.out2_id is not None and lay.out2_id in self.consumer_of:
                     c2, t2 = self.consumer_of[lay.out2_id], lay.out2_t
                     g2, g2_ld, g2_choff = c2.gin, c2.tin.ld, t2.choff
-                ops.bn_act_bwd(self.B, lay.H, lay.W, lay.cout, lay.y, lay.cout, 0, lay.scale, lay.shift, lay.mean,
+                cb = lay.n_act if lay.bn_narrow else lay.cout      # folded producer: the kept channels only
+                ops.bn_act_bwd(self.B, lay.H, lay.W, cb, lay.y, lay.cout, 0, lay.scale, lay.shift, lay.mean,
                                lay.invstd, lay.slope, lay.mode, cons.gin, cons.tin.ld, t.choff, lay.dy, lay.cout_p, 0,
                                gmap[id(lay.bn.weight)], gmap[id(lay.bn.bias)], S, g2, g2_ld or 0, g2_choff or 0,
-                               self.bwd_ws, lay.keep, lay.perm32, overflow=self.overflow)
+                               self.bwd_ws, None if lay.keep is None else lay.keep[:cb], None if lay.perm32 is None else lay.perm32[:cb],
+                               overflow=self.overflow, skip_dead_from=lay.n_act if lay.skip_dead else 0)
             mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
             dbias = gmap[id(lay.conv.bias)] if lay.conv.bias is not None else None
-            if lay.gather:
-                # kept filters only, in physical channel order; the finish kernel scatters to OIHW order.  Rows of
-                # removed filters are zero (as `grad * mask` makes them in the reference): zeroed here, not computed
-                gw = gmap[id(lay.conv.weight)]
-                if lay.perm is not None:
-                    gw.zero_()
-                self._timed('wgrad', lay, ops.conv_wgrad, lay.geom_act, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
-                            gw, mask, S, dbias, self.wgrad_ws, rows=lay.g_rows, cols=lay.g_cols)
-            elif side is None:
-                self._timed('wgrad', lay, ops.conv_wgrad, lay.geom, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
-                            gmap[id(lay.conv.weight)], mask, S, dbias, self.wgrad_ws)
+            def wgrad_of(ws):
+                """This block's weight gradient (nothing in the backward chain depends on it)."""
+                if lay.fold is not None:
+                    # kept input channels + the ones-channel: dense augmented gradient, then back to OIHW (the folded
+                    # column expands to the dead inputs) and to dbeta of the producer's dead channels (csrc/fold.hip)
+                    gw, prod = gmap[id(lay.conv.weight)], lay.fold
+                    if lay.perm is not None:
+                        gw.zero_()
+                    self._timed('wgrad', lay, ops.conv_wgrad, lay.geom_act, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
+                                lay.dwaug, None, S, dbias, ws)
+                    ops.unfold_wgrad(lay.conv.weight.data, mask, lay.g_rows, lay.g_cols, prod.bn.bias.data, prod.slope, lay.n_act,
+                                     lay.fold_cin, lay.dwaug, gw, gmap[id(prod.bn.bias)], gmap[id(prod.bn.weight)],
+                                     accumulate=prod.fold_consumers[0] is not lay)
+                elif lay.gather:
+                    # kept filters only, in physical channel order; the finish kernel scatters to OIHW order.  Rows of
+                    # removed filters are zero (as `grad * mask` makes them in the reference): zeroed here, not computed
+                    gw = gmap[id(lay.conv.weight)]
+                    if lay.perm is not None:
+                        gw.zero_()
+                    self._timed('wgrad', lay, ops.conv_wgrad, lay.geom_act, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
+                                gw, mask, S, dbias, ws, rows=lay.g_rows, cols=lay.g_cols)
+                else:
+                    self._timed('wgrad', lay, ops.conv_wgrad, lay.geom, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
+                                gmap[id(lay.conv.weight)], mask, S, dbias, ws)
+
+            if side is None:
+                wgrad_of(self.wgrad_ws)
             else:
-                # dY of this block is complete on the main stream: the weight gradient (which nothing in the
-                # backward chain depends on) runs beside the dgrad / BN-backward chain and fills its tails
+                # dY of this block is complete on the main stream: the weight gradient runs beside the dgrad /
+                # BatchNorm-backward chain on the second stream (own split-K workspace) and fills its tails
                 ev = torch.cuda.Event()
                 ev.record(main)
                 side.wait_event(ev)
                 with torch.cuda.stream(side):
-                    self._timed('wgrad', lay, ops.conv_wgrad, lay.geom, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
-                                gmap[id(lay.conv.weight)], mask, S, dbias, self._side_ws)
+                    wgrad_of(self._side_ws)
             if on_ready is not None:
                 if side is None:
                     on_ready(flat, lay.p_lo, lay.p_hi)

@@ -8,7 +8,8 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from ._lib import ConvGeom, ConvEpilogue, ActDesc, ActBwdDesc, ChanMap, PackJob, StemBlockDesc, check, ptr, stream_ptr
+from ._lib import (ConvGeom, ConvEpilogue, ActDesc, ActBwdDesc, ChanMap, PackJob, StemBlockDesc, FoldDesc, check, ptr,
+                   stream_ptr)
 
 HALF = torch.float16
 SLACK = 64  # fp16 elements of zeroed slack after every activation buffer
@@ -193,13 +194,47 @@ def _perm_ptr(perm, C_):
 
 
 def bn_coeffs(stats, C_, count, gamma, beta, rmean, rvar, training, scale, shift, mean=None, invstd=None,
-              momentum=0.1, eps=1e-5, perm=None):
-    """`perm` (int32 [C], optional): physical channel c uses gamma/beta/running_*[perm[c]]."""
+              momentum=0.1, eps=1e-5, perm=None, ones_channel=-1):
+    """`perm` (int32 [C], optional): physical channel c uses gamma/beta/running_*[perm[c]].
+    `ones_channel` >= 0: that physical channel gets scale 0 / shift 1 (the activation pass writes ones there)."""
     rows = stats.shape[0] if stats is not None else 0
     ld = stats.shape[2] if stats is not None else 0
-    check(L.lib().mcamd_bn_coeffs(ptr(stats), rows, ld, C_, count, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
-                                  momentum, eps, 1 if training else 0, ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
-                                  _perm_ptr(perm, C_), stream_ptr()), "mcamd_bn_coeffs")
+    check(L.lib().mcamd_bn_coeffs_ex(ptr(stats), rows, ld, C_, count, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
+                                     momentum, eps, 1 if training else 0, ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+                                     _perm_ptr(perm, C_), ones_channel, stream_ptr()), "mcamd_bn_coeffs_ex")
+
+
+def _fold_desc(w, mask, rows, cols, beta, slope, n, cin_k, aug):
+    _need_cuda(w, mask, rows, cols, beta)
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 4 and w.shape[2] == w.shape[3]
+    assert beta.dtype == torch.float32 and beta.numel() == w.shape[1]
+    d = FoldDesc()
+    d.w = w.data_ptr()
+    d.mask = mask.data_ptr() if mask is not None else None
+    for name, v, cnt in (("rows", rows, n), ("cols", cols, w.shape[1])):
+        if v is not None:
+            if v.dtype != torch.int32 or not v.is_contiguous() or v.numel() != cnt:
+                raise L.McamdError("fold: channel map `%s` must be a contiguous CUDA int32 vector of %d entries" % (name, cnt))
+            setattr(d, name, v.data_ptr())
+    d.beta, d.slope = beta.data_ptr(), slope
+    assert aug.dtype == torch.float32 and aug.is_contiguous() and aug.dim() == 4 and aug.shape[0] == n and aug.shape[1] > cin_k
+    d.n, d.cin_t, d.cin_k, d.cin_aug, d.ksize = n, w.shape[1], cin_k, aug.shape[1], w.shape[2]
+    return d
+
+
+def fold_weights(w, mask, rows, cols, beta, slope, n, cin_k, waug):
+    """Augmented weights [n][cin_aug >= cin_k + 1][k][k] of a consumer whose dead input channels are folded into one channel of
+    ones (include/mcamd.h, mcamd_fold_desc): kept inputs gathered, the last column = sum_c leaky(beta_c) W[:, c]."""
+    d = _fold_desc(w, mask, rows, cols, beta, slope, n, cin_k, waug)
+    check(L.lib().mcamd_fold_weights(C.byref(d), ptr(waug), stream_ptr()), "mcamd_fold_weights")
+
+
+def unfold_wgrad(w, mask, rows, cols, beta, slope, n, cin_k, dwaug, dw, prod_dbeta, prod_dgamma, accumulate=False):
+    """Augmented weight gradient -> OIHW dW (x mask; the folded column expands to the dead inputs), and the producer's
+    dbeta (dgamma = 0) for its dead channels."""
+    d = _fold_desc(w, mask, rows, cols, beta, slope, n, cin_k, dwaug)
+    check(L.lib().mcamd_unfold_wgrad(C.byref(d), ptr(dwaug), ptr(dw), ptr(prod_dbeta), ptr(prod_dgamma), 1 if accumulate else 0,
+                                     stream_ptr()), "mcamd_unfold_wgrad")
 
 
 def bn_act_fwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, slope, mode, dst, dst_ld, dst_choff=0, dst2=None,
@@ -225,8 +260,9 @@ def bn_act_fwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, slope, mode, dst, ds
 
 def bn_act_bwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, mean, invstd, slope, mode, g, g_ld, g_choff, dy, dy_ld,
                dy_choff, dgamma, dbeta, grad_scale=1.0, g2=None, g2_ld=0, g2_choff=0, workspace=None, dy_keep=None,
-               perm=None, overflow=None):
+               perm=None, overflow=None, skip_dead_from=0):
     d = ActBwdDesc()
+    d.skip_dead_param_grads = int(skip_dead_from)
     d.B, d.H, d.W, d.C = B, H, W, C_
     d.y, d.y_ld, d.y_choff = y.data_ptr(), y_ld, y_choff
     d.scale, d.shift, d.mean, d.invstd = scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr()

@@ -402,6 +402,55 @@ def test_stem_block_fwd_bwd(dev, B, H, W, masked, training):
     assert rel_l2(dgamma.cpu(), gl.grad) < TOL
 
 
+@pytest.mark.parametrize("k,cout_t,cin_t,n,cin_k,masked", [(3, 48, 40, 32, 16, True), (1, 64, 96, 64, 8, False), (3, 16, 24, 16, 0, True)])
+def test_fold_unfold_dead_inputs(dev, k, cout_t, cin_t, n, cin_k, masked):
+    """csrc/fold.hip against the algebra it implements: a consumer whose dead input channels hold the constants
+    leaky(beta_c) (zero halo) equals the same conv on  kept + one channel of ones  with the augmented weights, and
+    its weight / producer-beta gradients map back exactly (autograd of F.conv2d on the full problem, float64)."""
+    gen = torch.Generator().manual_seed(7 + k + cin_k)
+    B, H, W, slope = 2, 9, 7, 0.1
+    w = torch.randn(cout_t, cin_t, k, k, generator=gen)
+    mask = (torch.rand(cout_t, cin_t, k, k, generator=gen) > 0.3).float() if masked else None
+    rows = torch.randperm(cout_t, generator=gen)[:n]
+    cols = torch.randperm(cin_t, generator=gen)
+    beta = torch.randn(cin_t, generator=gen) * 0.3
+    xk = torch.randn(B, cin_k, H, W, generator=gen)
+    gy = torch.randn(B, n, H, W, generator=gen)
+    # reference: full input tensor with constants in the dead channels, autograd for dW and dbeta
+    wl = w.double().requires_grad_(True)
+    bl = beta.double().requires_grad_(True)
+    x_full = torch.zeros(B, cin_t, H, W, dtype=torch.float64)
+    x_full[:, cols[:cin_k]] = xk.double()
+    const = F.leaky_relu(bl, slope)[cols[cin_k:]].view(1, -1, 1, 1).expand(B, -1, H, W)
+    x_full = x_full.index_copy(1, cols[cin_k:], const)
+    weff = wl * mask.double() if masked else wl
+    yref = F.conv2d(x_full, weff[rows], None, 1, (k - 1) // 2)
+    (yref * gy.double()).sum().backward()
+    # device: augmented weights, the same conv on kept + ones in float64 torch, gradients through unfold
+    wd, md = w.to(dev), (mask.to(dev) if masked else None)
+    rd, cd, bd = rows.to(torch.int32).to(dev), cols.to(torch.int32).to(dev), beta.to(dev)
+    aug = (cin_k + 1 + 7) // 8 * 8            # channel counts are multiples of 8: zero-weight padding columns
+    waug = torch.full((n, aug, k, k), float("nan"), device=dev)
+    ops.fold_weights(wd, md, rd, cd, bd, slope, n, cin_k, waug)
+    assert float(waug[:, cin_k + 1:].abs().sum()) == 0.0
+    wa = waug.cpu().double().requires_grad_(True)
+    x_aug = torch.cat((xk.double(), torch.ones(B, 1, H, W, dtype=torch.float64),
+                       torch.randn(B, aug - cin_k - 1, H, W, generator=gen).double()), 1)
+    yaug = F.conv2d(x_aug, wa, None, 1, (k - 1) // 2)
+    assert rel_l2(yaug.detach(), yref.detach()) < 1e-5
+    (yaug * gy.double()).sum().backward()
+    dw = torch.zeros(cout_t, cin_t, k, k, device=dev)
+    dbeta, dgamma = torch.full((cin_t,), float("nan"), device=dev), torch.full((cin_t,), float("nan"), device=dev)
+    ops.unfold_wgrad(wd, md, rd, cd, bd, slope, n, cin_k, wa.grad.float().to(dev).contiguous(), dw, dbeta, dgamma)
+    gw = wl.grad * mask.double() if masked else wl.grad
+    assert rel_l2(dw.cpu(), gw) < 1e-5
+    dead = cols[cin_k:]
+    assert rel_l2(dbeta.cpu()[dead], bl.grad[dead]) < 1e-5 and float(dgamma.cpu()[dead].abs().max()) == 0.0
+    assert bool(torch.isnan(dbeta.cpu()[cols[:cin_k]]).all())          # kept channels are not this kernel's to write
+    ops.unfold_wgrad(wd, md, rd, cd, bd, slope, n, cin_k, wa.grad.float().to(dev).contiguous(), dw, dbeta, dgamma, accumulate=True)
+    assert rel_l2(dbeta.cpu()[dead], 2 * bl.grad[dead]) < 1e-5
+
+
 def _bn_ref(y, gamma, beta, slope, mode, training_stats=True):
     """fp32 reference of BN(train) -> leaky -> {plain, pool, reorg}; y is a leaf."""
     z = F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5)

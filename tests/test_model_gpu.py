@@ -210,11 +210,22 @@ def _teacher_forced(dev, cfg, B, seed, masked, hw=None, only=None, grad_scale=No
         worst[name] = max(worst.get(name, 0.0), val)
         assert val < tol, "%s of conv block %d: %.3e >= %.1e" % (name, lay.index, val, tol)
 
+    dead_expect, dead_idx, folded_producers = {}, {}, {}
     for lay in eng.layers:
         if only is not None and lay.li + 1 not in only:
             continue
         t = lay.tin
         X = unperm(padded_to_nchw(eng.bufs[t.buf], B, t.H, t.W, t.ld, t.C, t.choff), lay.in_perm)
+        fold_dead = None
+        if getattr(lay, "fold", None) is not None:
+            # this block folds its producer's dead channels (csrc/fold.hip): the buffer holds ONES in the first dead
+            # physical channel; the reference sees what the reference computes there, the constant leaky(beta)
+            prod = lay.fold
+            c0 = int(lay.in_perm[lay.fold_cin])
+            assert float((X[:, c0] - 1.0).abs().max()) == 0.0, "the ones-channel of a folded producer"
+            fold_dead = lay.in_perm[lay.fold_cin:].cpu()
+            # (with the BatchNorm pass narrowed to the kept channels the other dead channels are not even written)
+            X[:, fold_dead] = torch.nn.functional.leaky_relu(prod.bn.bias.detach().cpu()[fold_dead], prod.slope).view(1, -1, 1, 1)
         w = lay.conv.weight.detach().cpu()
         mask = lay.conv.mask.cpu() if lay.conv.mask_flag else None
         alive = None if lay.keep is None else unperm(lay.keep.cpu()[None], lay.perm)[0] != 0   # module order
@@ -298,8 +309,13 @@ def _teacher_forced(dev, cfg, B, seed, masked, hw=None, only=None, grad_scale=No
             operm = lay.perm
             if operm is not None and lay.mode == L.DST_REORG:
                 operm = torch.cat([operm + q * lay.cout for q in range(4)])
+            oexp = o.detach().clone()
+            if getattr(lay, "ones_idx", -1) >= 0:
+                if lay.bn_narrow:                                # the activation pass covers the kept channels only
+                    oexp[:, lay.perm[lay.n_act:].cpu()] = 0.0
+                oexp[:, int(lay.perm[lay.ones_idx])] = 1.0       # the ones-channel its folding consumers read
             rec("bn_act_fwd", rel_l2(unperm(padded_to_nchw(eng.bufs[ot.buf], B, ot.H, ot.W, ot.ld, ot.C, ot.choff), operm),
-                                     o.detach()), 1e-3, lay)
+                                     oexp), 1e-3, lay)
             cons = eng.consumer_of[lay.out_id]
             G = unperm(raw_to_nchw(cons.gin, B, ot.H, ot.W, cons.tin.ld, ot.C, ot.choff), operm) / S
             loss = (o * G).sum()
@@ -324,6 +340,15 @@ def _teacher_forced(dev, cfg, B, seed, masked, hw=None, only=None, grad_scale=No
                         c, float(pc[c]), float(var[c]), float(y[:, c].double().mean()),
                         float(dyref[:, c].double().norm()), None if alive is None else bool(alive[c])))
             rec("bn_act_bwd", rel_l2(dy, dyref), 2e-3, lay)
+            if getattr(lay, "skip_dead", False):
+                # dgamma / dbeta of the folded dead channels come from the consumers (checked after the loop): G holds
+                # nothing for them, so the BatchNorm backward is compared on the channels it computes
+                live = torch.zeros(lay.cout, dtype=torch.bool)
+                live[lay.perm[:lay.n_act].cpu()] = True
+                assert float(lay.bn.weight.grad.cpu()[~live].abs().max()) == 0.0
+                folded_producers[lay.li] = (lay, ~live)
+                gam.grad[~live] = 0.0
+                bet.grad[~live] = lay.bn.bias.grad.cpu()[~live]
             rec("dgamma", rel_l2(lay.bn.weight.grad.cpu(), gam.grad), 2e-3, lay)
             if rel_l2(lay.bn.bias.grad.cpu(), bet.grad) >= 2e-3:      # diagnostic: which channels carry the error
                 db, dbr = lay.bn.bias.grad.cpu().double(), bet.grad.double()
@@ -350,7 +375,26 @@ def _teacher_forced(dev, cfg, B, seed, masked, hw=None, only=None, grad_scale=No
             rec("dbias", rel_l2(lay.conv.bias.grad.cpu(), dy.sum((0, 2, 3))), 1e-3, lay)
         if lay.gin is not None:
             gin = unperm(raw_to_nchw(lay.gin, B, lay.H, lay.W, lay.tin.ld, lay.tin.C, lay.tin.choff), lay.in_perm) / S
-            rec("dgrad", rel_l2(gin, Xl.grad), 1e-3, lay)
+            gref = Xl.grad
+            if fold_dead is not None:
+                prod = lay.fold
+                beta = prod.bn.bias.detach().cpu()
+                lp = torch.where(beta[fold_dead] > 0, torch.ones(()), torch.full((), prod.slope))
+                dead_expect[prod.li] = dead_expect.get(prod.li, 0) + (lp * gref[:, fold_dead].double().sum((0, 2, 3))).float()
+                dead_idx[prod.li] = fold_dead
+                c0 = int(lay.in_perm[lay.fold_cin])
+                keepm = torch.ones(gin.shape[1], dtype=torch.bool)
+                keepm[fold_dead] = False
+                assert float(gin[:, fold_dead[1:]].abs().max() if fold_dead.numel() > 1 else 0.0) == 0.0
+                gin, gref = gin[:, keepm], gref[:, keepm]
+            rec("dgrad", rel_l2(gin, gref), 1e-3, lay)
+    # dbeta of the folded dead channels: sum over every consumer of leaky'(beta) * sum_p (reference dX of that consumer)
+    for li, (prod, deadm) in folded_producers.items():
+        if li in dead_expect and all(only is None or c.li + 1 in only for c in prod.fold_consumers):
+            got = prod.bn.bias.grad.cpu()[dead_idx[li]]
+            rec("dbeta_folded", rel_l2(got, dead_expect[li]), 2e-3, prod)
+    if folded_producers:
+        print("folded producers: %s" % sorted(p.li + 1 for p, _ in folded_producers.values()))
     print("teacher-forced worst rel-L2 per kernel:", {k: "%.1e" % v for k, v in worst.items()})
 
 
