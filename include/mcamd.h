@@ -281,6 +281,14 @@ typedef struct mcamd_fold_desc {
     int32_t n, cin_t, cin_k, cin_aug, ksize;
 } mcamd_fold_desc;
 int mcamd_fold_weights(const mcamd_fold_desc* d, float* waug, void* stream);
+/* Every folding layer of a network in ONE launch (the per-step rebuild of engine.py): `jobs_dev` is a DEVICE array of
+ * `njobs` descriptors; first_block = sum of d.n over the preceding jobs, total_blocks = sum over all jobs. */
+typedef struct mcamd_fold_job {
+    mcamd_fold_desc d;
+    float* waug;
+    int64_t first_block;
+} mcamd_fold_job;
+int mcamd_fold_weights_many(const mcamd_fold_job* jobs_dev, int32_t njobs, int64_t total_blocks, void* stream);
 /* dw_oihw rows outside rows[] are not written (the caller zeroes them).  prod_dbeta / prod_dgamma: the producer's
  * gradient vectors in the module's order; dead channels receive dbeta (`accumulate` != 0: added to what an earlier
  * consumer of the same producer wrote) and dgamma = 0. */

@@ -80,6 +80,10 @@ class StemBlockDesc(C.Structure):
                 ("dw", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
 
 
+class FoldJob(C.Structure):
+    _fields_ = [("d", FoldDesc), ("waug", C.c_void_p), ("first_block", C.c_int64)]
+
+
 EPI_RAW_F16, EPI_NCHW_F32, EPI_PAD_F16, EPI_RAW_F32 = 0, 1, 2, 3
 DST_PLAIN, DST_POOL, DST_REORG = 0, 1, 2
 
@@ -103,6 +107,7 @@ SIGNATURES = {
     "mcamd_bn_coeffs": (C.c_int, [_P, _I32, _I32, _I32, _I64, _P, _P, _P, _P, _F, _F, _I32, _P, _P, _P, _P, _P, _P]),
     "mcamd_bn_coeffs_ex": (C.c_int, [_P, _I32, _I32, _I32, _I64, _P, _P, _P, _P, _F, _F, _I32, _P, _P, _P, _P, _P, _I32, _P]),
     "mcamd_fold_weights": (C.c_int, [C.POINTER(FoldDesc), _P, _P]),
+    "mcamd_fold_weights_many": (C.c_int, [_P, _I32, _I64, _P]),
     "mcamd_unfold_wgrad": (C.c_int, [C.POINTER(FoldDesc), _P, _P, _P, _P, _I32, _P]),
     "mcamd_bn_act_fwd": (C.c_int, [C.POINTER(ActDesc), _P]),
     "mcamd_bn_act_bwd_workspace_bytes": (_SZ, [C.POINTER(ActBwdDesc)]),

@@ -32,11 +32,10 @@ namespace {
 
 __device__ __forceinline__ float leaky_of(float b, float slope) { return b > 0.f ? b : b * slope; }
 
-__global__ __launch_bounds__(256) void fold_weights_kernel(const float* w, const float* mask, const int* rows, const int* cols,
-                                                           const float* beta, float slope, int cin_t, int cin_k, int cin_aug,
-                                                           int kk, float* waug) {
-    __shared__ float red[256 * 9];
-    const int n = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void fold_one_filter(float* red, int n, const float* w, const float* mask, const int* rows,
+                                                const int* cols, const float* beta, float slope, int cin_t, int cin_k, int cin_aug,
+                                                int kk, float* waug) {
+    const int tid = threadIdx.x;
     const long long rbase = (long long)(rows ? rows[n] : n) * cin_t * kk;
     float* dst = waug + (long long)n * cin_aug * kk;
     for (int idx = (cin_k + 1) * kk + tid; idx < cin_aug * kk; idx += 256) dst[idx] = 0.f;   // alignment padding of the channel count
@@ -67,6 +66,27 @@ __global__ __launch_bounds__(256) void fold_weights_kernel(const float* w, const
         __syncthreads();
     }
     if (tid < kk) dst[cin_k * kk + tid] = red[tid * 256];
+}
+
+__global__ __launch_bounds__(256) void fold_weights_kernel(const float* w, const float* mask, const int* rows, const int* cols,
+                                                           const float* beta, float slope, int cin_t, int cin_k, int cin_aug,
+                                                           int kk, float* waug) {
+    __shared__ float red[256 * 9];
+    fold_one_filter(red, blockIdx.x, w, mask, rows, cols, beta, slope, cin_t, cin_k, cin_aug, kk, waug);
+}
+
+// every folding layer of a network in one launch: block -> (job, filter) through the jobs' first_block prefix sums
+__global__ __launch_bounds__(256) void fold_weights_many_kernel(const mcamd_fold_job* jobs, int njobs) {
+    __shared__ float red[256 * 9];
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (long long)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const mcamd_fold_job j = jobs[lo];
+    fold_one_filter(red, (int)(blockIdx.x - j.first_block), j.d.w, j.d.mask, (const int*)j.d.rows, (const int*)j.d.cols, j.d.beta,
+                    j.d.slope, j.d.cin_t, j.d.cin_k, j.d.cin_aug, j.d.ksize * j.d.ksize, j.waug);
 }
 
 __global__ __launch_bounds__(256) void unfold_wgrad_kernel(const float* dwaug, const float* w, const float* mask, const int* rows,
@@ -132,6 +152,13 @@ extern "C" int mcamd_fold_weights(const mcamd_fold_desc* d, float* waug, void* s
     hipLaunchKernelGGL(fold_weights_kernel, dim3(d->n), dim3(256), 0, (hipStream_t)stream, d->w, d->mask, (const int*)d->rows,
                        (const int*)d->cols, d->beta, d->slope, d->cin_t, d->cin_k, d->cin_aug, d->ksize * d->ksize, waug);
     MCAMD_LAUNCH_CHECK("fold_weights");
+    return MCAMD_OK;
+}
+
+extern "C" int mcamd_fold_weights_many(const mcamd_fold_job* jobs_dev, int32_t njobs, int64_t total_blocks, void* stream) {
+    MCAMD_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "fold_weights_many: empty job table");
+    hipLaunchKernelGGL(fold_weights_many_kernel, dim3((int)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
+    MCAMD_LAUNCH_CHECK("fold_weights_many");
     return MCAMD_OK;
 }
 

@@ -430,10 +430,23 @@ class Engine:
             if lay.stem:
                 mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
                 ops.pack_weights(lay.geom_act, lay.conv.weight.data, mask, True, False, lay.wp, None, rows=lay.g_rows)
-        for lay in self.layers:
-            if lay.fold is not None:
+        folds = [lay for lay in self.layers if lay.fold is not None]
+        if folds and self._training:
+            # training: the folded constants are leaky(beta) of the producers' own parameter tensors -> one launch for
+            # all layers through a cached job table (the table holds pointers: rebuilt when a tensor moved)
+            fkey = tuple((lay.conv.weight.data_ptr(), lay.fold.bn.bias.data_ptr(),
+                          lay.conv.mask.data_ptr() if lay.conv.mask_flag else 0) for lay in folds)
+            if fkey != getattr(self, "_fold_key", None):
+                self._fold_table = ops.fold_table([dict(w=lay.conv.weight.data, mask=lay.conv.mask if lay.conv.mask_flag else None,
+                                                        rows=lay.g_rows, cols=lay.g_cols, beta=lay.fold.bn.bias.data,
+                                                        slope=lay.fold.slope, n=lay.n_act, cin_k=lay.fold_cin, waug=lay.waug)
+                                                   for lay in folds], self.device)
+                self._fold_key = fkey
+            ops.fold_many(*self._fold_table)
+        else:
+            for lay in folds:       # eval: the constants come from the running statistics (a temporary per forward)
                 mask = lay.conv.mask if lay.conv.mask_flag else None
-                ops.fold_weights(lay.conv.weight.data, mask, lay.g_rows, lay.g_cols, self._fold_constants(lay.fold, self._training),
+                ops.fold_weights(lay.conv.weight.data, mask, lay.g_rows, lay.g_cols, self._fold_constants(lay.fold, False),
                                  lay.fold.slope, lay.n_act, lay.fold_cin, lay.waug)
         if self._pack_table is not None:
             ops.pack_many(*self._pack_table)
@@ -552,6 +565,7 @@ class Engine:
         for lay in self.layers:
             lay.fold, lay.ones_idx, lay.skip_dead, lay.fold_consumers, lay.bn_narrow = None, -1, False, [], False
             lay.waug = lay.dwaug = None
+            self._fold_key = None
             if lay.gin is not None:
                 lay.gin.zero_()       # a folding consumer's dgrad leaves the dead channels of G untouched: they must be finite
         if not (self.compact and os.environ.get("MCAMD_FOLD_DEAD", "1") == "1"):

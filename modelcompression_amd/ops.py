@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from ._lib import (ConvGeom, ConvEpilogue, ActDesc, ActBwdDesc, ChanMap, PackJob, StemBlockDesc, FoldDesc, check, ptr,
+from ._lib import (ConvGeom, ConvEpilogue, ActDesc, ActBwdDesc, ChanMap, PackJob, StemBlockDesc, FoldDesc, FoldJob, check, ptr,
                    stream_ptr)
 
 HALF = torch.float16
@@ -227,6 +227,25 @@ def fold_weights(w, mask, rows, cols, beta, slope, n, cin_k, waug):
     ones (include/mcamd.h, mcamd_fold_desc): kept inputs gathered, the last column = sum_c leaky(beta_c) W[:, c]."""
     d = _fold_desc(w, mask, rows, cols, beta, slope, n, cin_k, waug)
     check(L.lib().mcamd_fold_weights(C.byref(d), ptr(waug), stream_ptr()), "mcamd_fold_weights")
+
+
+def fold_table(jobs, device):
+    """jobs: list of dicts(w, mask, rows, cols, beta, slope, n, cin_k, waug) -> (device table, njobs, total blocks) for
+    `fold_many` (mcamd_fold_job array).  The tensors must stay alive and in place while the table is used."""
+    arr = (FoldJob * len(jobs))()
+    total = 0
+    for a, j in zip(arr, jobs):
+        a.d = _fold_desc(j["w"], j["mask"], j["rows"], j["cols"], j["beta"], j["slope"], j["n"], j["cin_k"], j["waug"])
+        a.waug = j["waug"].data_ptr()
+        a.first_block = total
+        total += j["n"]
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return host.to(device), len(jobs), total
+
+
+def fold_many(table, njobs, total):
+    """Every folding layer's augmented weights in one launch."""
+    check(L.lib().mcamd_fold_weights_many(ptr(table), njobs, total, stream_ptr()), "mcamd_fold_weights_many")
 
 
 def unfold_wgrad(w, mask, rows, cols, beta, slope, n, cin_k, dwaug, dw, prod_dbeta, prod_dgamma, accumulate=False):
