@@ -99,6 +99,7 @@ class GradReducer:
         self._kept = None            # static-mask transport: sorted int64 indices of the kept entries of the flat buffer
         self._kept_pos = None        # {flat offset: number of kept entries below it} at the parameter boundaries
         self._kept_total = 0
+        self.prescaled = False       # attach(): the engine already divides every gradient by the world size
 
     # ---- static masks: only the kept entries travel
     def set_static_masks(self, params, masks):
@@ -213,7 +214,8 @@ class GradReducer:
                 cb()
         self._pending = []
         self._lo = self._hi = self._sent_lo = None
-        flat.div_(self.world)
+        if not self.prescaled:
+            flat.div_(self.world)
         return flat
 
     def reduce_flat(self, flat):
@@ -227,11 +229,12 @@ class GradReducer:
         if not self.active or not grads:
             return
         flat = torch.cat([g.reshape(-1) for g in grads])
-        kept, self._kept = self._kept, None      # separate gradient tensors: dense transport
+        kept, self._kept = self._kept, None      # separate gradient tensors: dense transport ...
+        pre, self.prescaled = self.prescaled, False   # ... and nobody divided them by the world size yet
         try:
             self.reduce_flat(flat)
         finally:
-            self._kept = kept
+            self._kept, self.prescaled = kept, pre
         off = 0
         for g in grads:
             g.copy_(flat[off:off + g.numel()].view_as(g))
@@ -246,6 +249,9 @@ def attach(model, reducer=None, masks=None):
         reducer.set_static_masks(model.parameters(), masks)
     model._grad_ready_hook = reducer.ready      # called per final tail slice during backward
     model._grad_hook = reducer.finish           # called once at the end of backward
+    # averaging rides on the kernels' 1 / grad_scale factor (engine.py backward): no division pass after the all-reduce
+    model._grad_div = float(reducer.world) if reducer.active else 1.0
+    reducer.prescaled = True
     return reducer
 
 

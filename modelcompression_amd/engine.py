@@ -711,6 +711,10 @@ class Engine:
         (layers finish last-to-first, so the slices walk down from the tail): dp.GradReducer
         starts its all-reduce buckets there."""
         S = self.grad_scale
+        # data parallel: every PARAMETER gradient leaves the kernels already divided by the world size (it rides on the
+        # 1 / grad_scale factor their finish passes apply anyway), so the summed all-reduce result is the average and no
+        # separate 202 MB division pass follows it (dp.attach sets model._grad_div)
+        D = S * float(getattr(self.model, "_grad_div", 1.0))
         # every element is written below (wgrad finish / dgamma / dbeta / dbias): no memset needed
         flat = torch.empty(self.total_params, dtype=torch.float32, device=self.device)
         views = [flat[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.params)]
@@ -735,7 +739,7 @@ class Engine:
                 self._timed('wgrad', lay, ops.stem_block_bwd, self.B, lay.H, lay.W, self.bufs[lay.tin.buf], lay.wp,
                             lay.bn.weight.data, lay.scale, lay.shift, lay.mean, lay.invstd, lay.slope, cons.gin, cons.tin.ld,
                             lay.out_t.choff, gmap[id(lay.conv.weight)], gmap[id(lay.bn.weight)], gmap[id(lay.bn.bias)],
-                            lay.stem_ws, mask=mask, grad_scale=S)
+                            lay.stem_ws, mask=mask, grad_scale=D)
                 if on_ready is not None:
                     if side is None:
                         on_ready(flat, lay.p_lo, lay.p_hi)
@@ -758,7 +762,7 @@ class Engine:
                 cb = lay.n_act if lay.bn_narrow else lay.cout      # folded producer: the kept channels only
                 ops.bn_act_bwd(self.B, lay.H, lay.W, cb, lay.y, lay.cout, 0, lay.scale, lay.shift, lay.mean,
                                lay.invstd, lay.slope, lay.mode, cons.gin, cons.tin.ld, t.choff, lay.dy, lay.cout_p, 0,
-                               gmap[id(lay.bn.weight)], gmap[id(lay.bn.bias)], S, g2, g2_ld or 0, g2_choff or 0,
+                               gmap[id(lay.bn.weight)], gmap[id(lay.bn.bias)], D, g2, g2_ld or 0, g2_choff or 0,
                                self.bwd_ws, None if lay.keep is None else lay.keep[:cb], None if lay.perm32 is None else lay.perm32[:cb],
                                overflow=self.overflow, skip_dead_from=lay.n_act if lay.skip_dead else 0)
             mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
@@ -772,7 +776,7 @@ class Engine:
                     if lay.perm is not None:
                         gw.zero_()
                     self._timed('wgrad', lay, ops.conv_wgrad, lay.geom_act, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
-                                lay.dwaug, None, S, dbias, ws)
+                                lay.dwaug, None, D, dbias, ws)
                     ops.unfold_wgrad(lay.conv.weight.data, mask, lay.g_rows, lay.g_cols, prod.bn.bias.data, prod.slope, lay.n_act,
                                      lay.fold_cin, lay.dwaug, gw, gmap[id(prod.bn.bias)], gmap[id(prod.bn.weight)],
                                      accumulate=prod.fold_consumers[0] is not lay)
@@ -783,10 +787,10 @@ class Engine:
                     if lay.perm is not None:
                         gw.zero_()
                     self._timed('wgrad', lay, ops.conv_wgrad, lay.geom_act, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
-                                gw, mask, S, dbias, ws, rows=lay.g_rows, cols=lay.g_cols)
+                                gw, mask, D, dbias, ws, rows=lay.g_rows, cols=lay.g_cols)
                 else:
                     self._timed('wgrad', lay, ops.conv_wgrad, lay.geom, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
-                                gmap[id(lay.conv.weight)], mask, S, dbias, ws)
+                                gmap[id(lay.conv.weight)], mask, D, dbias, ws)
 
             if side is None:
                 wgrad_of(self.wgrad_ws)
