@@ -316,7 +316,7 @@ int mcamd_unfold_wgrad(const mcamd_fold_desc* d, const float* dwaug, float* dw_o
  * stats == NULL provides them from the running statistics).
  * ------------------------------------------------------------------------- */
 typedef struct mcamd_stem_block_desc {
-    int32_t B, H, W;                      /* conv resolution; cin = 3, cout = 32 */
+    int32_t B, H, W;                      /* conv resolution; cin = 3 */
     const void* x;
     const void* wp;
     const float* gamma; const float* beta;
@@ -332,6 +332,9 @@ typedef struct mcamd_stem_block_desc {
     float grad_scale;
     float* dw;                            /* out: OIHW fp32, x mask, / grad_scale */
     float* dgamma; float* dbeta;          /* out fp32 [32], / grad_scale (may be NULL) */
+    int32_t cout;                         /* filters: 32 (0 is read as 32); 8, 16 or 24 are accepted by the forward pass with
+                                             training == 0 (physically slim models): `dst` still receives 32 channels, the
+                                             ones past cout as zeros, and scale / shift hold cout entries */
 } mcamd_stem_block_desc;
 size_t mcamd_stem_block_workspace_bytes(void);
 int mcamd_stem_block_fwd(const mcamd_stem_block_desc* d, void* workspace, size_t workspace_bytes, void* stream);

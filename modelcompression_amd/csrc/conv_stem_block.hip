@@ -41,6 +41,7 @@ struct StemBlockArgs {
     float* slab;            // per workgroup partial results
     int out_ld, out_choff, g_ld, g_choff;
     int B, H, W, H2, W2, Wb;   // Wb = W / 32
+    int cout;                  // filters computed (<= 32; the forward pass writes zeros behind them)
     long long nunits;
     float slope;
 };
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256) void stem_block_fwd_kernel(StemBlockArgs a) {
     h8_t wf[3];
 #pragma unroll
     for (int ty = 0; ty < 3; ++ty) wf[ty] = *(const h8_t*)(a.w + (long long)pl * 96 + ty * 32 + 8 * kg);
-    const float sc = a.scale[pl], sh = a.shift[pl];
+    const float sc = pl < a.cout ? a.scale[pl] : 0.f, sh = pl < a.cout ? a.shift[pl] : 0.f;   // slim models: fewer than 32 filters
     half_t* tw = tile[wave];
     const int nunits = (int)a.nunits;
     const int wstride = gridDim.x * 4 * UN;
@@ -546,6 +547,8 @@ int check_desc(const mcamd_stem_block_desc* d, const char* what) {
     MCAMD_REQUIRE(d->W % 32 == 0 && d->H % 2 == 0, "%s: needs W %% 32 == 0 and an even H (got %d x %d)", what, d->H, d->W);
     MCAMD_REQUIRE((long long)d->B * d->H * d->W < (1ll << 31), "%s: more than 2^31 output pixels", what);
     MCAMD_REQUIRE(d->x && d->wp && d->scale && d->shift, "%s: null argument", what);
+    MCAMD_REQUIRE(d->cout == 0 || d->cout == 32 || (d->cout > 0 && d->cout < 32 && d->cout % 8 == 0 && !d->training),
+                  "%s: cout %d (32; 8 / 16 / 24 for the inference-mode forward pass only)", what, d->cout);
     return MCAMD_OK;
 }
 
@@ -556,6 +559,7 @@ void fill_args(StemBlockArgs& a, const mcamd_stem_block_desc* d) {
     a.scale = d->scale, a.shift = d->shift;
     a.B = d->B, a.H = d->H, a.W = d->W, a.H2 = d->H / 2, a.W2 = d->W / 2, a.Wb = d->W / 32;
     a.slope = d->slope;
+    a.cout = d->cout > 0 ? d->cout : 32;
 }
 
 }  // namespace
@@ -610,6 +614,7 @@ extern "C" int mcamd_stem_block_fwd(const mcamd_stem_block_desc* d, void* worksp
 extern "C" int mcamd_stem_block_bwd(const mcamd_stem_block_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
     if (check_desc(d, "stem_block_bwd")) return MCAMD_EINVAL;
     MCAMD_REQUIRE(workspace && d->g && d->dw && d->gamma && d->save_mean && d->save_invstd, "stem_block_bwd: null argument");
+    MCAMD_REQUIRE(d->cout == 0 || d->cout == 32, "stem_block_bwd: training needs 32 filters (got %d)", d->cout);
     MCAMD_REQUIRE(d->g_ld % 8 == 0 && d->g_choff % 8 == 0 && d->g_choff + 32 <= d->g_ld,
                   "stem_block_bwd: gradient slice [%d, %d) does not fit g_ld %d", d->g_choff, d->g_choff + 32, d->g_ld);
     MCAMD_REQUIRE(d->grad_scale > 0.f, "stem_block_bwd: grad_scale must be positive");

@@ -302,6 +302,10 @@ class Engine:
             lay.fused_stem = bool(lay.stem and lay.bn is not None and lay.mode == L.DST_POOL and lay.out2_id is None
                                   and lay.cout == 32 and lay.W % 32 == 0 and lay.H % 2 == 0 and lay.border is None
                                   and os.environ.get("MCAMD_STEM_FUSED", "1") == "1")
+            # physically slim models keep 8 / 16 / 24 filters here: the inference-mode forward takes the same kernel
+            lay.fused_stem_eval = bool(lay.stem and lay.bn is not None and lay.mode == L.DST_POOL and lay.out2_id is None
+                                       and lay.cout in (8, 16, 24) and lay.W % 32 == 0 and lay.H % 2 == 0 and lay.border is None
+                                       and os.environ.get("MCAMD_STEM_FUSED", "1") == "1")
             lay.dy = None if lay.fused_stem else ops.alloc_padded(B, lay.H, lay.W, lay.cout_p, dev)
             lay.keep, lay.keep_key = None, None
             lay.gin = None
@@ -651,7 +655,7 @@ class Engine:
                     out += lay.border_map
                 continue
             bn = lay.bn
-            if lay.fused_stem:
+            if lay.fused_stem or (lay.fused_stem_eval and not training and lay.out_t.ld - lay.out_t.choff >= 32):
                 # conv1 + BatchNorm + LeakyReLU + maxpool in one pass over the image (batch statistics from the Gram
                 # matrix of the image windows in training mode, running statistics otherwise)
                 if not training:
@@ -660,8 +664,8 @@ class Engine:
                 t = lay.out_t
                 self._timed('fwd', lay, ops.stem_block_fwd, B, lay.H, lay.W, xin, lay.wp, bn.weight.data, bn.bias.data,
                             bn.running_mean, bn.running_var, training, lay.scale, lay.shift, lay.mean, lay.invstd, lay.slope,
-                            self.bufs[t.buf], t.ld, t.choff, lay.stem_ws,
-                            momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps)
+                            self.bufs[t.buf], t.ld, t.choff, lay.stem_ws if lay.fused_stem else None,
+                            momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps, cout=lay.cout)
                 continue
             if self.precise:
                 # unrounded fp32 raw output (+ batch statistics from the fp32 values), then BN + LeakyReLU

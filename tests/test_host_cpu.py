@@ -285,6 +285,46 @@ def test_data_parallel_reducer_gloo_world2(tmp_path):
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
 
 
+def _dp_rehearsal_worker(tmp):
+    """MCAMD_DP_REHEARSE=1 with ONE rank (gloo): the process group exists, the reducer's bucketed asynchronous collectives
+    run, and -- being a sum over one rank, with the averaging riding on the engine's 1 / grad_scale -- leave the gradient
+    bit-identical.  This is the mode a 1-GPU box uses to execute every RCCL call of the N > 1 path."""
+    import torch.distributed as dist
+    from modelcompression_amd import dp
+    os.environ["MCAMD_DP_REHEARSE"] = "1"
+    for k in ("RANK", "WORLD_SIZE", "MASTER_PORT", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    assert dp.init_from_env("gloo") == (0, 1) and dist.is_initialized() and dist.get_world_size() == 1
+    red = dp.GradReducer(bucket_elems=1000)
+    assert red.active and red.world == 1
+    flat = torch.randn(5000)
+    ref = flat.clone()
+    for lo, hi in ((4000, 5000), (2500, 4000), (0, 2500)):
+        red.ready(flat, lo, hi)
+    red.finish(flat)
+    assert torch.equal(flat, ref) and red.collectives >= 3 and red.bytes_reduced == 5000 * 4
+
+    class M:      # what dp.attach touches
+        def parameters(self):
+            return []
+    m = M()
+    r2 = dp.attach(m)
+    assert r2.prescaled and m._grad_div == 1.0 and m._grad_hook == r2.finish
+    assert dp.all_ranks_ok(True) is True and dp.all_ranks_ok(False) is False
+    dist.destroy_process_group()
+    open(os.path.join(tmp, "ok"), "w").write("1")
+
+
+def test_data_parallel_one_rank_rehearsal(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_dp_rehearsal_worker_entry, args=(str(tmp_path),), nprocs=1, join=True)
+    assert os.path.exists(tmp_path / "ok")
+
+
+def _dp_rehearsal_worker_entry(rank, tmp):
+    _dp_rehearsal_worker(tmp)
+
+
 def test_region_loss_matches_reference_golden():
     """RegionLoss + build_targets (nets.py:282-635) against values recorded from the reference
     (CPU shims, tests/golden/gen_golden.py::gen_region_loss): loss and d(loss)/d(output)."""

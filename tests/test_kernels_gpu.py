@@ -402,6 +402,33 @@ def test_stem_block_fwd_bwd(dev, B, H, W, masked, training):
     assert rel_l2(dgamma.cpu(), gl.grad) < TOL
 
 
+@pytest.mark.parametrize("cout", [8, 24])
+def test_stem_block_fwd_slim_filters(dev, cout):
+    """Inference-mode forward of the fused first block with fewer than 32 filters (physically slim models): the kept
+    channels match the reference ops, the channels behind them are written as zeros."""
+    B, H, W = 2, 32, 64
+    gen = torch.Generator().manual_seed(50 + cout)
+    x = torch.rand(B, 3, H, W, generator=gen)
+    w = torch.randn(cout, 3, 3, 3, generator=gen) * 0.3
+    gamma, beta = torch.rand(cout, generator=gen) + 0.5, torch.randn(cout, generator=gen) * 0.2
+    rm, rv = torch.randn(cout, generator=gen) * 0.1, torch.rand(cout, generator=gen) + 0.5
+    ref = F.max_pool2d(F.leaky_relu(F.batch_norm(F.conv2d(q16(x), q16(w), None, 1, 1), rm.clone(), rv.clone(), gamma, beta, False,
+                                                 0.1, 1e-5), 0.1), 2, 2)
+    xb, _ = to_padded(x.to(dev))
+    g = ops.geom(B, H, W, 3, 3, cout, 4, 0, stem=1)
+    wp, _ = ops.pack_weights(g, w.to(dev).contiguous())
+    scale, shift = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
+    ops.bn_coeffs(None, cout, 1, gamma.to(dev), beta.to(dev), rm.to(dev), rv.to(dev), False, scale, shift)
+    dst = ops.alloc_padded(B, H // 2, W // 2, 32, dev)
+    dst.fill_(float("nan"))
+    ops.padded_view(dst, B, H // 2, W // 2, 32)[:] = 0
+    ops.padded_view(dst, B, H // 2, W // 2, 32)[:, 1:-1, 1:-1] = float("nan")
+    ops.stem_block_fwd(B, H, W, xb, wp, None, None, None, None, False, scale, shift, None, None, 0.1, dst, 32, 0, None, cout=cout)
+    assert rel_l2(padded_to_nchw(dst, B, H // 2, W // 2, 32, cout, 0), ref) < TOL
+    assert float(padded_to_nchw(dst, B, H // 2, W // 2, 32, 32, 0)[:, cout:].abs().max()) == 0.0
+    assert halo_is_zero(dst, B, H // 2, W // 2, 32)
+
+
 @pytest.mark.parametrize("k,cout_t,cin_t,n,cin_k,masked", [(3, 48, 40, 32, 16, True), (1, 64, 96, 64, 8, False), (3, 16, 24, 16, 0, True)])
 def test_fold_unfold_dead_inputs(dev, k, cout_t, cin_t, n, cin_k, masked):
     """csrc/fold.hip against the algebra it implements: a consumer whose dead input channels hold the constants
