@@ -355,9 +355,10 @@ static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot, bool raw_epi
         if (pp && ktot >= 256 && n >= 128 && M >= 256) {
             bool use = pp == 2;
             int bm = 256, bn = 256;
-            // K >= 1152 for any layer; 3x3 layers from K = 576 (conv3/5 forward 0.183 -> 0.176 ms); the short-K 1x1 layers
-            // gain < 10 % and are tiny
-            if (pp == 1 && (ktot >= 1152 || (ktot >= env_int("MCAMD_PP_MINK", 512) && ktot == 9 * cin_tap))) {
+            // K >= 1152 for any layer.  (3x3 layers from K = 576, MCAMD_PP_MINK=512, looked like a gain at first -- conv3/5
+            // forward 0.183 -> 0.176 ms in one run -- but measured back to back on one box the whole step is 0.5 % slower with
+            // it: 9.846 / 9.836 vs 9.800 / 9.782 ms, conv3/5 forward 0.186 vs 0.174 ms in the event pass.)
+            if (pp == 1 && (ktot >= 1152 || (ktot >= env_int("MCAMD_PP_MINK", 1152) && ktot == 9 * cin_tap))) {
                 // Measured (profiles/): per busy CU the ping-pong tile is ~1.27x the 192x128 tile, but
                 // it runs ONE workgroup per CU, so it only pays when its tiles fill the 256 CUs well: 256 or 192 rows,
                 // 256 or 128 columns (128 columns stage 1.3x the bytes per flop: costed at 0.8 of the 256-column rate),
