@@ -552,6 +552,42 @@ def test_yolov2_train_step_vs_oracle(dev):
         assert ge < 1.5 * gf + 5e-3, (name, ge, gf)
 
 
+@pytest.mark.parametrize("masks,B", [(None, 64), ("filter40", 32)], ids=["dense-b64", "filter40-b32"])
+def test_training_step_is_bit_reproducible(dev, masks, B):
+    """Every reduction of a training step has a fixed order (split-K slabs, BatchNorm slabs, the Gram and gradient slabs of
+    the fused first block, the folded-weight sums) and no kernel uses floating-point atomics: the same step run three times
+    -- weight gradients overlapped on the second stream, as in production -- gives bit-identical logits and gradients.
+    At the bench's batch the free-running LDS-DMA rings and the register-staged windows of the first block see real memory
+    latencies, which is where an ordering bug would show."""
+    blocks = O.parse_cfg(YOLOV2_VOC_CFG)
+    m = nets.Darknet(YOLOV2_VOC_CFG)
+    m.load_state_dict(O.init_state(blocks, seed=3))
+    m.to(dev).train()
+    if masks:
+        from modelcompression_amd.pruning.weightPruning.methods import quick_filter_prune
+        m.set_masks(quick_filter_prune(m, 40.0))
+        m.grad_scale = 16.0
+    g = torch.Generator().manual_seed(17)
+    x = torch.rand(B, 3, 416, 416, generator=g).to(dev)
+    state = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    runs = []
+    for _ in range(3):
+        m.load_state_dict(state)               # (the forward pass updates the running statistics)
+        out = m(x)
+        m.zero_grad()
+        out.float().mean().backward()
+        runs.append((out.detach().clone(), m._last_flat_grad.clone()))
+    eng = list(m._engines.values())[0]
+    assert eng.overlap_wgrad and eng.layers[0].fused_stem
+    if masks:
+        assert any(lay.fold is not None for lay in eng.layers)
+    assert bool(torch.isfinite(runs[0][1]).all())
+    for o, gflat in runs[1:]:
+        assert torch.equal(o, runs[0][0]), "logits differ between identical steps"
+        assert torch.equal(gflat, runs[0][1]), "gradients differ between identical steps: %d of %d elements" % (
+            int((gflat != runs[0][1]).sum()), gflat.numel())
+
+
 def test_cpu_tensor_raises(dev):
     m, _, _ = _mini_model(dev)
     with pytest.raises(RuntimeError):
