@@ -335,6 +335,11 @@ typedef struct mcamd_stem_block_desc {
     int32_t cout;                         /* filters: 32 (0 is read as 32); 8, 16 or 24 are accepted by the forward pass with
                                              training == 0 (physically slim models): `dst` still receives 32 channels, the
                                              ones past cout as zeros, and scale / shift hold cout entries */
+    int32_t planes;                       /* forward: 1 (0 is read as 1), or 3 = split storage of the pooled output as in
+                                             mcamd_act_desc.planes: hi | lo | hi in three ADJACENT 32-channel planes
+                                             [dst_choff, dst_choff + 96) -- the "mixed" precision mode keeps plain fp16
+                                             operands on this block (image and weights: 5.2e-4 -> 5.4e-4 on the logits,
+                                             tools/error_budget.py) but hands its consumer an unrounded activation */
 } mcamd_stem_block_desc;
 size_t mcamd_stem_block_workspace_bytes(void);
 int mcamd_stem_block_fwd(const mcamd_stem_block_desc* d, void* workspace, size_t workspace_bytes, void* stream);

@@ -77,7 +77,7 @@ class StemBlockDesc(C.Structure):
                 ("dst", C.c_void_p), ("dst_ld", C.c_int32), ("dst_choff", C.c_int32),
                 ("g", C.c_void_p), ("g_ld", C.c_int32), ("g_choff", C.c_int32),
                 ("mask", C.c_void_p), ("grad_scale", C.c_float),
-                ("dw", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("cout", C.c_int32)]
+                ("dw", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("cout", C.c_int32), ("planes", C.c_int32)]
 
 
 class FoldJob(C.Structure):

@@ -282,9 +282,10 @@ __global__ __launch_bounds__(1024) void stem_coeffs_kernel(const double* csum, c
 // 16-byte pieces (1 KB contiguous when dst_ld == 32).
 __device__ __forceinline__ int pooled_of(int q, int kg) { return (q & 1) + 4 * (q >> 1) + 2 * kg; }   // pooled pixel of register pair q
 
-template <int UN>
+template <int UN, int PL>   // PL = 3: split (hi | lo | hi) storage of the pooled output (32 channels per plane, adjacent planes)
 __global__ __launch_bounds__(256) void stem_block_fwd_kernel(StemBlockArgs a) {
-    __shared__ __attribute__((aligned(16))) half_t tile[4][16 * 32];
+    constexpr int TW = 32 * PL;                       // halfs per pooled pixel in the tile
+    __shared__ __attribute__((aligned(16))) half_t tile[4][16 * TW];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 31, kg = lane >> 5;
@@ -332,13 +333,24 @@ __global__ __launch_bounds__(256) void stem_block_fwd_kernel(StemBlockArgs a) {
                 const float z10 = __builtin_fmaf(acc1[2 * q], sc, sh), z11 = __builtin_fmaf(acc1[2 * q + 1], sc, sh);
                 float m = fmaxf(fmaxf(z00, z01), fmaxf(z10, z11));
                 m = m > 0.f ? m : m * a.slope;
-                tw[pooled_of(q, kg) * 32 + pl] = (half_t)fminf(fmaxf(m, -65504.f), 65504.f);
+                m = fminf(fmaxf(m, -65504.f), 65504.f);
+                const half_t hi = (half_t)m;
+                half_t* tp = tw + pooled_of(q, kg) * TW + pl;
+                tp[0] = hi;
+                if (PL == 3) {                        // exact difference, one rounding; a consumer with split operands reads all three
+                    tp[32] = (half_t)(m - (float)hi);
+                    tp[64] = hi;
+                }
             }
-            const int prow = lane >> 2, pc = lane & 3;
-            const h8_t v = *(const h8_t*)(tw + prow * 32 + pc * 8);
-            if (u0 + i < nunits)
-                *(h8_t*)(a.out + ((long long)(ub[i] * (a.H2 + 2) + uh[i] + 1) * (a.W2 + 2) + uw[i] * 16 + prow + 1) * a.out_ld +
-                         a.out_choff + pc * 8) = v;
+#pragma unroll
+            for (int k = 0; k < PL; ++k) {
+                const int piece = lane + 64 * k;
+                const int prow = piece / (4 * PL), pc = piece - prow * (4 * PL);
+                const h8_t v = *(const h8_t*)(tw + prow * TW + pc * 8);
+                if (u0 + i < nunits)
+                    *(h8_t*)(a.out + ((long long)(ub[i] * (a.H2 + 2) + uh[i] + 1) * (a.W2 + 2) + uw[i] * 16 + prow + 1) * a.out_ld +
+                             a.out_choff + pc * 8) = v;
+            }
         }
     }
 }
@@ -568,8 +580,10 @@ extern "C" size_t mcamd_stem_block_workspace_bytes(void) { return carve().total;
 
 extern "C" int mcamd_stem_block_fwd(const mcamd_stem_block_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
     if (check_desc(d, "stem_block_fwd")) return MCAMD_EINVAL;
-    MCAMD_REQUIRE(d->dst && d->dst_ld % 8 == 0 && d->dst_choff % 8 == 0 && d->dst_choff + 32 <= d->dst_ld,
-                  "stem_block_fwd: output slice [%d, %d) does not fit dst_ld %d", d->dst_choff, d->dst_choff + 32, d->dst_ld);
+    MCAMD_REQUIRE(d->planes == 0 || d->planes == 1 || d->planes == 3, "stem_block_fwd: planes must be 1 or 3 (got %d)", d->planes);
+    const int span = d->planes == 3 ? 96 : 32;
+    MCAMD_REQUIRE(d->dst && d->dst_ld % 8 == 0 && d->dst_choff % 8 == 0 && d->dst_choff + span <= d->dst_ld,
+                  "stem_block_fwd: output slice [%d, %d) does not fit dst_ld %d", d->dst_choff, d->dst_choff + span, d->dst_ld);
     const Carve c = carve();
     hipStream_t st = (hipStream_t)stream;
     StemBlockArgs a;
@@ -604,9 +618,10 @@ extern "C" int mcamd_stem_block_fwd(const mcamd_stem_block_desc* d, void* worksp
     const int grid = (int)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
     const char* e_un = getenv("MCAMD_STEM_FWD_UN");   // tuning switch
     const int un = e_un ? atoi(e_un) : 4;
-    if (un == 4) hipLaunchKernelGGL(stem_block_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, a);
-    else if (un == 1) hipLaunchKernelGGL(stem_block_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(stem_block_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, a);
+    if (d->planes == 3) hipLaunchKernelGGL((stem_block_fwd_kernel<2, 3>), dim3(grid), dim3(256), 0, st, a);
+    else if (un == 4) hipLaunchKernelGGL((stem_block_fwd_kernel<4, 1>), dim3(grid), dim3(256), 0, st, a);
+    else if (un == 1) hipLaunchKernelGGL((stem_block_fwd_kernel<1, 1>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((stem_block_fwd_kernel<2, 1>), dim3(grid), dim3(256), 0, st, a);
     MCAMD_LAUNCH_CHECK("stem_block_fwd");
     return MCAMD_OK;
 }

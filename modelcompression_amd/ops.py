@@ -328,7 +328,7 @@ def _stem_desc(B, H, W, x, wp, gamma, beta, scale, shift, mean, invstd, slope):
 
 
 def stem_block_fwd(B, H, W, x, wp, gamma, beta, rmean, rvar, training, scale, shift, mean, invstd, slope, dst, dst_ld,
-                   dst_choff, workspace, momentum=0.1, eps=1e-5, cout=32):
+                   dst_choff, workspace, momentum=0.1, eps=1e-5, cout=32, planes=1):
     """The first block in one call: conv1 (3 -> 32, 3x3) + BatchNorm + LeakyReLU + MaxPool(2,2) from the NHWC4 image
     `x` to the pooled padded-NHWC `dst`; the raw conv output is never stored (include/mcamd.h, mcamd_stem_block_desc).
     training: batch statistics from the image windows' Gram matrix, scale / shift / mean / invstd are written."""
@@ -336,7 +336,7 @@ def stem_block_fwd(B, H, W, x, wp, gamma, beta, rmean, rvar, training, scale, sh
     d.running_mean = rmean.data_ptr() if rmean is not None else None
     d.running_var = rvar.data_ptr() if rvar is not None else None
     d.momentum, d.eps, d.training = momentum, eps, 1 if training else 0
-    d.cout = cout
+    d.cout, d.planes = cout, planes
     d.dst, d.dst_ld, d.dst_choff = dst.data_ptr(), dst_ld, dst_choff
     check(L.lib().mcamd_stem_block_fwd(C.byref(d), ptr(workspace), workspace.numel() if workspace is not None else 0,
                                        stream_ptr()), "mcamd_stem_block_fwd")
