@@ -20,6 +20,7 @@ Activations live in HBM as padded NHWC fp16 for the whole step; weights are re-p
 (fp32 master * mask -> fp16) once per optimizer step.  All buffers are allocated once per
 batch size; a B=64 training step holds ~7 GB of the 288 GB.
 """
+import contextlib
 import os
 
 import torch
@@ -444,26 +445,45 @@ class Engine:
             if lay.stem:
                 mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
                 ops.pack_weights(lay.geom_act, lay.conv.weight.data, mask, True, False, lay.wp, None, rows=lay.g_rows)
-        folds = [lay for lay in self.layers if lay.fold is not None]
-        if folds and self._training:
-            # training: the folded constants are leaky(beta) of the producers' own parameter tensors -> one launch for
-            # all layers through a cached job table (the table holds pointers: rebuilt when a tensor moved)
-            fkey = tuple((lay.conv.weight.data_ptr(), lay.fold.bn.bias.data_ptr(),
-                          lay.conv.mask.data_ptr() if lay.conv.mask_flag else 0) for lay in folds)
-            if fkey != getattr(self, "_fold_key", None):
-                self._fold_table = ops.fold_table([dict(w=lay.conv.weight.data, mask=lay.conv.mask if lay.conv.mask_flag else None,
-                                                        rows=lay.g_rows, cols=lay.g_cols, beta=lay.fold.bn.bias.data,
-                                                        slope=lay.fold.slope, n=lay.n_act, cin_k=lay.fold_cin, waug=lay.waug)
-                                                   for lay in folds], self.device)
-                self._fold_key = fkey
-            ops.fold_many(*self._fold_table)
-        else:
-            for lay in folds:       # eval: the constants come from the running statistics (a temporary per forward)
-                mask = lay.conv.mask if lay.conv.mask_flag else None
-                ops.fold_weights(lay.conv.weight.data, mask, lay.g_rows, lay.g_cols, self._fold_constants(lay.fold, False),
-                                 lay.fold.slope, lay.n_act, lay.fold_cin, lay.waug)
-        if self._pack_table is not None:
-            ops.pack_many(*self._pack_table)
+        # The layers behind the first block are not needed until that block's forward is done: with folded layers
+        # (filter masks) their fold + re-pack runs on the second stream under the first block's Gram / forward kernels and
+        # forward() makes the launch stream wait for it in front of the second block (self._pack_event): 7.17 -> 7.10 ms
+        # per filter-pruned step.  Dense: the lone re-pack launch gains nothing from it (9.69 vs 9.73 ms), so it stays on
+        # the launch stream (MCAMD_OVERLAP_PACK=1 forces the overlap, 0 forbids it).
+        self._pack_event = None
+        side = None
+        want = os.environ.get("MCAMD_OVERLAP_PACK", "auto")
+        if (training and self.overlap_wgrad and self.events is None and self.layers[0].fused_stem
+                and (want == "1" or (want == "auto" and any(lay.fold is not None for lay in self.layers)))):
+            main = torch.cuda.current_stream(self.device)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(self.device)
+            side = self._side_stream
+            side.wait_stream(main)            # the optimizer step that produced these weights
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            folds = [lay for lay in self.layers if lay.fold is not None]
+            if folds and self._training:
+                # training: the folded constants are leaky(beta) of the producers' own parameter tensors -> one launch for
+                # all layers through a cached job table (the table holds pointers: rebuilt when a tensor moved)
+                fkey = tuple((lay.conv.weight.data_ptr(), lay.fold.bn.bias.data_ptr(),
+                              lay.conv.mask.data_ptr() if lay.conv.mask_flag else 0) for lay in folds)
+                if fkey != getattr(self, "_fold_key", None):
+                    self._fold_table = ops.fold_table([dict(w=lay.conv.weight.data, mask=lay.conv.mask if lay.conv.mask_flag else None,
+                                                            rows=lay.g_rows, cols=lay.g_cols, beta=lay.fold.bn.bias.data,
+                                                            slope=lay.fold.slope, n=lay.n_act, cin_k=lay.fold_cin, waug=lay.waug)
+                                                       for lay in folds], self.device)
+                    self._fold_key = fkey
+                ops.fold_many(*self._fold_table)
+            else:
+                for lay in folds:       # eval: the constants come from the running statistics (a temporary per forward)
+                    mask = lay.conv.mask if lay.conv.mask_flag else None
+                    ops.fold_weights(lay.conv.weight.data, mask, lay.g_rows, lay.g_cols, self._fold_constants(lay.fold, False),
+                                     lay.fold.slope, lay.n_act, lay.fold_cin, lay.waug)
+            if self._pack_table is not None:
+                ops.pack_many(*self._pack_table)
+            if side is not None:
+                self._pack_event = torch.cuda.Event()
+                self._pack_event.record(side)
         self._packed_sig = sig
         self.model._weights_dirty = False
 
@@ -658,6 +678,9 @@ class Engine:
         out = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
         for lay in self.layers:
             xin = self.bufs[lay.tin.buf]
+            if lay.li == 1 and getattr(self, "_pack_event", None) is not None:
+                torch.cuda.current_stream(self.device).wait_event(self._pack_event)     # re-pack on the second stream
+                self._pack_event = None
             if lay.is_last:
                 bias = lay.conv.bias.data if lay.conv.bias is not None else None
                 self._timed('fwd', lay, ops.conv_fwd_nchw, lay.geom_f if self.precise else lay.geom_act, xin, lay.wp, out, bias)
