@@ -743,6 +743,17 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ backward
+    def bn_act_bwd_layer(self, lay, g, g_ld, g_choff, g2, g2_ld, g2_choff, dy, dgamma, dbeta, grad_scale):
+        """pool / reorg / route + LeakyReLU + BatchNorm backward of one block: G (gradient wrt the block's output, at the
+        consumer's channel slice) -> dY (padded NHWC), dgamma, dbeta.  One place for the launch arguments (narrowed to the
+        kept channels for a folded producer); tests re-issue it with a substitute G."""
+        cb = lay.n_act if lay.bn_narrow else lay.cout
+        ops.bn_act_bwd(self.B, lay.H, lay.W, cb, lay.y, lay.cout, 0, lay.scale, lay.shift, lay.mean,
+                       lay.invstd, lay.slope, lay.mode, g, g_ld, g_choff, dy, lay.cout_p, 0,
+                       dgamma, dbeta, grad_scale, g2, g2_ld, g2_choff,
+                       self.bwd_ws, None if lay.keep is None else lay.keep[:cb], None if lay.perm32 is None else lay.perm32[:cb],
+                       overflow=self.overflow, skip_dead_from=lay.n_act if lay.skip_dead else 0)
+
     def backward(self, grad_out, on_ready=None):
         """grad wrt the returned logits -> one flat fp32 gradient buffer; returns per-parameter views.
         `on_ready(flat, lo, hi)` is called as soon as every kernel writing flat[lo:hi] is enqueued
@@ -797,12 +808,8 @@ class Engine:
                 if lay.out2_id is not None and lay.out2_id in self.consumer_of:
                     c2, t2 = self.consumer_of[lay.out2_id], lay.out2_t
                     g2, g2_ld, g2_choff = c2.gin, c2.tin.ld, t2.choff
-                cb = lay.n_act if lay.bn_narrow else lay.cout      # folded producer: the kept channels only
-                ops.bn_act_bwd(self.B, lay.H, lay.W, cb, lay.y, lay.cout, 0, lay.scale, lay.shift, lay.mean,
-                               lay.invstd, lay.slope, lay.mode, cons.gin, cons.tin.ld, t.choff, lay.dy, lay.cout_p, 0,
-                               gmap[id(lay.bn.weight)], gmap[id(lay.bn.bias)], D, g2, g2_ld or 0, g2_choff or 0,
-                               self.bwd_ws, None if lay.keep is None else lay.keep[:cb], None if lay.perm32 is None else lay.perm32[:cb],
-                               overflow=self.overflow, skip_dead_from=lay.n_act if lay.skip_dead else 0)
+                self.bn_act_bwd_layer(lay, cons.gin, cons.tin.ld, t.choff, g2, g2_ld or 0, g2_choff or 0, lay.dy,
+                                      gmap[id(lay.bn.weight)], gmap[id(lay.bn.bias)], D)
             mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
             dbias = gmap[id(lay.conv.bias)] if lay.conv.bias is not None else None
             def wgrad_of(ws):

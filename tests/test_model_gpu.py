@@ -210,7 +210,7 @@ def _teacher_forced(dev, cfg, B, seed, masked, hw=None, only=None, grad_scale=No
         worst[name] = max(worst.get(name, 0.0), val)
         assert val < tol, "%s of conv block %d: %.3e >= %.1e" % (name, lay.index, val, tol)
 
-    dead_expect, dead_idx, folded_producers = {}, {}, {}
+    dead_expect, dead_idx, folded_producers, nk = {}, {}, {}, {}
     for lay in eng.layers:
         if only is not None and lay.li + 1 not in only:
             continue
@@ -318,13 +318,41 @@ def _teacher_forced(dev, cfg, B, seed, masked, hw=None, only=None, grad_scale=No
                                      oexp), 1e-3, lay)
             cons = eng.consumer_of[lay.out_id]
             G = unperm(raw_to_nchw(cons.gin, B, ot.H, ot.W, cons.tin.ld, ot.C, ot.choff), operm) / S
-            loss = (o * G).sum()
+            G2 = c2 = t2 = None
             if lay.out2_id is not None and lay.out2_id in eng.consumer_of:
                 c2, t2 = eng.consumer_of[lay.out2_id], lay.out2_t
                 G2 = unperm(raw_to_nchw(c2.gin, B, lay.H, lay.W, c2.tin.ld, t2.C, t2.choff), lay.perm) / S
+            # LeakyReLU is not differentiable at 0: where the pre-activation lies within rounding of it, the kernel's side
+            # (fp32 fma of the stored y) and the reference's (torch's BatchNorm formula) may differ, both validly, and with
+            # the network's heavy-tailed G ONE such element moves a dbeta entry by its whole |G| (seen: conv16 of the
+            # 40 % model, one channel 87 % off, the other 1023 at 1e-6).  Those elements (a handful per layer) are taken out
+            # of the comparison on both sides: G is zeroed there and the product's backward entry point is issued again.
+            kink = F.batch_norm(y, None, None, gam.detach(), bet.detach(), True, 0.1, 1e-5).abs() < 1e-5
+            eng_dy, eng_dg, eng_db = lay.dy, lay.bn.weight.grad, lay.bn.bias.grad
+            if bool(kink.any()):
+                kg = kink.float()
+                badG = (F.max_pool2d(kg, 2, 2) if lay.mode == L.DST_POOL else O.reorg(kg, 2) if lay.mode == L.DST_REORG else kg) > 0
+                G = G.masked_fill(badG, 0.0)
+                if G2 is not None:
+                    G2 = G2.masked_fill(kink, 0.0)
+                from util import nchw_to_raw
+
+                def phys(t, perm):      # module channel order -> the engine's physical order
+                    return t if perm is None else t[:, perm.cpu()]
+                gbuf = nchw_to_raw(phys(G, operm) * S, cons.tin.ld, ot.choff)
+                g2buf = nchw_to_raw(phys(G2, lay.perm) * S, c2.tin.ld, t2.choff) if G2 is not None else None
+                eng_dy = ops.alloc_padded(B, lay.H, lay.W, lay.cout_p, dev)
+                eng_dg, eng_db = lay.bn.weight.grad.clone(), lay.bn.bias.grad.clone()
+                eng.bn_act_bwd_layer(lay, gbuf, cons.tin.ld, ot.choff, g2buf, c2.tin.ld if c2 is not None else 0,
+                                     t2.choff if t2 is not None else 0, eng_dy, eng_dg, eng_db, S)
+                nk["kinks"] = nk.get("kinks", 0) + int(kink.sum())
+            loss = (o * G).sum()
+            if G2 is not None:
                 loss = loss + (a * G2).sum()
             loss.backward()
-            dy = unperm(padded_to_nchw(lay.dy, B, lay.H, lay.W, lay.cout_p, lay.cout), lay.perm) / S
+            dy = unperm(padded_to_nchw(eng_dy, B, lay.H, lay.W, lay.cout_p, lay.cout), lay.perm) / S
+            # (the step's own weight / input gradients below were computed from the step's own dY)
+            dy_step = dy if eng_dy is lay.dy else unperm(padded_to_nchw(lay.dy, B, lay.H, lay.W, lay.cout_p, lay.cout), lay.perm) / S
             dyref = yl.grad
             if alive is not None:
                 # a removed filter's dY is written as 0 (`dy_keep`): nothing reads it -- its weights are zero, so dgrad
@@ -348,10 +376,10 @@ def _teacher_forced(dev, cfg, B, seed, masked, hw=None, only=None, grad_scale=No
                 assert float(lay.bn.weight.grad.cpu()[~live].abs().max()) == 0.0
                 folded_producers[lay.li] = (lay, ~live)
                 gam.grad[~live] = 0.0
-                bet.grad[~live] = lay.bn.bias.grad.cpu()[~live]
-            rec("dgamma", rel_l2(lay.bn.weight.grad.cpu(), gam.grad), 2e-3, lay)
-            if rel_l2(lay.bn.bias.grad.cpu(), bet.grad) >= 2e-3:      # diagnostic: which channels carry the error
-                db, dbr = lay.bn.bias.grad.cpu().double(), bet.grad.double()
+                bet.grad[~live] = eng_db.cpu()[~live]
+            rec("dgamma", rel_l2(eng_dg.cpu(), gam.grad), 2e-3, lay)
+            if rel_l2(eng_db.cpu(), bet.grad) >= 2e-3:      # diagnostic: which channels carry the error
+                db, dbr = eng_db.cpu().double(), bet.grad.double()
                 for c in torch.argsort((db - dbr).abs(), descending=True)[:8].tolist():
                     print("    dbeta channel %d: engine %.6e reference %.6e, beta %.3e, alive %s" % (
                         c, float(db[c]), float(dbr[c]), float(bet[c]), None if alive is None else bool(alive[c])))
@@ -364,8 +392,10 @@ def _teacher_forced(dev, cfg, B, seed, masked, hw=None, only=None, grad_scale=No
                               float(yc.mean()), float(yc.var(unbiased=False)), float(lay.mean[pc_]), float(lay.invstd[pc_]),
                               float(lay.scale[pc_]), float(lay.shift[pc_]), float(gam[c]),
                               int(((zref > 0) != (zeng.double() > 0)).sum()), yc.numel(), float(zref.abs().min())))
-            rec("dbeta", rel_l2(lay.bn.bias.grad.cpu(), bet.grad), 2e-3, lay)
+            rec("dbeta", rel_l2(eng_db.cpu(), bet.grad), 2e-3, lay)
         # wgrad / dgrad from the engine's dY
+        if not lay.is_last:
+            dy = dy_step
         yref.backward(dy.to(rdt))
         gw = wq.grad * mask if mask is not None else wq.grad
         rec("wgrad", rel_l2(lay.conv.weight.grad.cpu(), gw), 1e-3, lay)
@@ -395,6 +425,7 @@ def _teacher_forced(dev, cfg, B, seed, masked, hw=None, only=None, grad_scale=No
             rec("dbeta_folded", rel_l2(got, dead_expect[li]), 2e-3, prod)
     if folded_producers:
         print("folded producers: %s" % sorted(p.li + 1 for p, _ in folded_producers.values()))
+    print("elements within 1e-5 of the LeakyReLU kink taken out of the BatchNorm-backward comparisons: %d" % nk.get("kinks", 0))
     print("teacher-forced worst rel-L2 per kernel:", {k: "%.1e" % v for k, v in worst.items()})
 
 
