@@ -395,6 +395,13 @@ static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot, bool raw_epi
         }
     t.bm = 128;
     t.bn = best;
+    // Few tiles (the 13x13 layers at the per-GPU batch of BASELINE configs[3], B = 32: M = 5 408 -> 43 x 4 tiles of 128 x 128
+    // for N = 512, 172 workgroups on 256 CUs): 64-column tiles double the workgroups at 2/3 of the per-tile rate
+    // (dgrad total at B = 32: 1.69 -> 1.65 ms per step, 6.235 -> 6.22 ms per step; nothing changes at B = 64)
+    if (t.bn == 128 && n % 64 == 0 && env_int("MCAMD_NARROW_FILL", 1)) {
+        const long long t128 = ((M + 127) / 128) * ((n + 127) / 128);
+        if (t128 < 256 && 2 * t128 <= 512) t.bn = 64;
+    }
     int want_bk = env_int("MCAMD_BK", 64);
     t.bk = (want_bk == 64 && cin_tap % 64 == 0) ? 64 : 32;
     // Tile quantisation: 2 workgroups per CU = 512 slots.  A 192-row tile (wave tile 96x64) often turns
