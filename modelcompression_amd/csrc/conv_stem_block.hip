@@ -56,23 +56,25 @@ __device__ __forceinline__ long long uniform_off(long long v) {
 }
 
 // Position of a work unit (image b, unit row h, 32-column block w) in 32-bit arithmetic, stepped incrementally: a
-// 64-bit decode of the unit index per step cost more instructions than the step's MFMAs.
+// 64-bit decode of the unit index per step cost more instructions than the step's MFMAs.  Units are numbered DOWN a
+// 32-pixel column strip first (h fastest): consecutive units of a wave share image rows (3 of 3 + 1 for the Gram steps,
+// 2 of 4 for the two-row units), which then come from its own L1 / L2 instead of being fetched again by another XCD.
 struct UnitPos {
     int b, h, w;
 };
 __device__ __forceinline__ UnitPos unit_decode(int u, int Wb, int Hn) {
     UnitPos p;
-    p.w = u % Wb;
-    const int t = u / Wb;
-    p.h = t % Hn;
-    p.b = t / Hn;
+    p.h = u % Hn;
+    const int t = u / Hn;
+    p.w = t % Wb;
+    p.b = t / Wb;
     return p;
 }
-__device__ __forceinline__ void unit_advance(UnitPos& p, const UnitPos& d, int Wb, int Hn) {   // p += d (d < one image row range)
-    p.w += d.w;
-    if (p.w >= Wb) p.w -= Wb, ++p.h;
+__device__ __forceinline__ void unit_advance(UnitPos& p, const UnitPos& d, int Wb, int Hn) {   // p += d (d from unit_decode)
     p.h += d.h;
-    if (p.h >= Hn) p.h -= Hn, ++p.b;
+    if (p.h >= Hn) p.h -= Hn, ++p.w;
+    p.w += d.w;
+    if (p.w >= Wb) p.w -= Wb, ++p.b;
     p.b += d.b;
 }
 
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(512, 4) void stem_gram_kernel(StemBlockArgs a) {   
     const int wstride = gridDim.x * NW * GD;
     int u0 = (blockIdx.x * NW + wave) * GD;
     UnitPos pos = unit_decode(u0 < nunits ? u0 : 0, a.Wb, a.H);
-    const UnitPos dstep = unit_decode(wstride - (GD - 1), a.Wb, a.H), one = {0, 0, 1};
+    const UnitPos dstep = unit_decode(wstride - (GD - 1), a.Wb, a.H), one = {0, 1, 0};
     const unsigned row_elems = (a.W + 2) * 4, lane_off = (pl + 2 * kg) * 4;
     auto reads = [&](int buf, Frag (&fb)[2], Frag (&fc)[2]) {
         const unsigned o = buf * PERW;
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256) void stem_block_fwd_kernel(StemBlockArgs a) {
     const int wstride = gridDim.x * 4 * UN;
     int u0 = (blockIdx.x * 4 + wave) * UN;
     UnitPos pos = unit_decode(u0 < nunits ? u0 : 0, a.Wb, a.H2);
-    const UnitPos dstep = unit_decode(wstride - (UN - 1), a.Wb, a.H2), one = {0, 0, 1};
+    const UnitPos dstep = unit_decode(wstride - (UN - 1), a.Wb, a.H2), one = {0, 1, 0};
     const unsigned row_elems = (a.W + 2) * 4, lane_off = (pl + 2 * kg) * 4;
     for (; u0 < nunits; u0 += wstride) {
         h8_t xr[UN][4];
