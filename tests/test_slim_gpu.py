@@ -88,12 +88,16 @@ def test_slim_yolov2_60pct_b128(dev, tmp_path):
         assert e < 5e-3
         times = {}
         for name, net in (("dense", m), ("slim", s)):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
+            # best of three single forwards: deep into a long test process the caching allocator sometimes has to go
+            # back to hipMalloc for the 265 MB input conversion, which put 8 ms into one of three averaged runs
+            best = float("inf")
             for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
                 net(x)
-            torch.cuda.synchronize()
-            times[name] = (time.perf_counter() - t0) / 3
+                torch.cuda.synchronize()
+                best = min(best, time.perf_counter() - t0)
+            times[name] = best
     print("B=128 eval forward: masked dense %.1f ms (%.0f img/s), slim %.1f ms (%.0f img/s)"
           % (times["dense"] * 1e3, 128 / times["dense"], times["slim"] * 1e3, 128 / times["slim"]))
     assert times["slim"] < times["dense"]
