@@ -88,10 +88,12 @@ def test_slim_yolov2_60pct_b128(dev, tmp_path):
         assert e < 5e-3
         times = {}
         for name, net in (("dense", m), ("slim", s)):
-            # best of three single forwards: deep into a long test process the caching allocator sometimes has to go
-            # back to hipMalloc for the 265 MB input conversion, which put 8 ms into one of three averaged runs
+            # best of five single forwards, not a mean: behind the 4-minute test_model_gpu.py in one process the mean of
+            # three slim forwards came out at 20 ms once (12 ms for the masked-dense net, logits correct, 6 ms when the
+            # file runs alone) -- a one-off stall (most likely the caching allocator going back to hipMalloc for the
+            # 265 MB input conversion), not the kernels' time, which is what this assertion is about
             best = float("inf")
-            for _ in range(3):
+            for _ in range(5):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 net(x)
