@@ -278,6 +278,7 @@ def main():
     import torch
     import torch.distributed as dist
     from modelcompression_amd import nets, dp, YOLOV2_VOC_CFG, ops
+    from modelcompression_amd import engine as engine_mod
     from modelcompression_amd.synthetic import init_synthetic, synthetic_batch
 
     # MCAMD_DP_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N>1 path on a 1-GPU box)
@@ -441,6 +442,9 @@ def main():
                        wl_name, B, {"dense": 1, "filter40": 2, "weight80": 3}[args.workload]),
                    "global_batch": world * B, "input": "3x416x416", "parallelism": "dp%d" % world,
                    "grad_scale": model.grad_scale,
+                   # engine.py _get_side_stream: the weight-gradient stream was PROBED to run beside the launch stream
+                   # (None: overlap off or probe disabled; False: no concurrent stream found, the step is serialised)
+                   "second_stream_concurrent": next(iter(engine_mod.Engine._SIDE_STREAMS.values()), (None, None))[1],
                    "conv_tflops_whole_step": round(value * FWD_BWD_GFLOP_PER_IMG / 1e3, 1),
                    "frac_of_fp16_mfma_peak_whole_step": round(value * FWD_BWD_GFLOP_PER_IMG / 1e3 / (PEAK_FP16_TFLOPS * world), 4),
                    "conv_kernel_ms_per_step": {k: round(v[0], 3) for k, v in tot.items()},

@@ -173,8 +173,10 @@ class GradReducer:
         self._pending.append((works[-1], done))
 
     # ---- overlapped path: the engine reports gradient slices as they become final (tail first)
-    def ready(self, flat, lo, hi):
-        """`flat[lo:hi]` is final (all kernels that write it are enqueued on the current stream).
+    def ready(self, flat, lo, hi, fence=None):
+        """`flat[lo:hi]` is final (all kernels that write it are enqueued on the current stream -- or, with `fence`,
+        will be visible inside the stream context `fence()` returns: the engine's two-stream backward passes one, and it
+        is entered only when a bucket is really launched).
         Slices arrive in descending, contiguous order; a collective is launched whenever the
         accumulated slice reaches `bucket_elems` (of travelling elements)."""
         if not self.active:
@@ -190,7 +192,11 @@ class GradReducer:
         if self._kept is not None and self._lo in self._kept_pos and self._hi in self._kept_pos:
             n = self._kept_pos[self._hi] - self._kept_pos[self._lo]
         if n >= self.bucket:
-            self._launch(flat)
+            if fence is not None:
+                with fence():
+                    self._launch(flat)
+            else:
+                self._launch(flat)
 
     def _launch(self, flat):
         if self._hi is None or self._hi == self._lo:
@@ -247,7 +253,10 @@ def attach(model, reducer=None, masks=None):
     reducer = reducer or GradReducer()
     if masks is not None:
         reducer.set_static_masks(model.parameters(), masks)
-    model._grad_ready_hook = reducer.ready      # called per final tail slice during backward
+    def ready(flat, lo, hi, fence=None):        # called per final tail slice during backward
+        reducer.ready(flat, lo, hi, fence)
+    ready.takes_fence = True
+    model._grad_ready_hook = ready
     model._grad_hook = reducer.finish           # called once at the end of backward
     # averaging rides on the kernels' 1 / grad_scale factor (engine.py backward): no division pass after the all-reduce
     model._grad_div = float(reducer.world) if reducer.active else 1.0

@@ -70,6 +70,33 @@ PLAIN_BLOCK_ERR = 2.9e-4
 MIXED_BUDGET = 5.5e-4
 
 
+def _probe_side_stream(device, tries=8):
+    """(stream, concurrent): see Engine._get_side_stream.  MCAMD_SIDE_PROBE=0 takes the first stream unprobed."""
+    if os.environ.get("MCAMD_SIDE_PROBE", "1") != "1":
+        return torch.cuda.Stream(device), None
+    main = torch.cuda.current_stream(device)
+    big = torch.empty(64 << 20, dtype=torch.float32, device=device)       # 256 MB: ~0.1 ms per pass
+    tiny = torch.zeros(64, dtype=torch.float32, device=device)
+    first = None
+    for _ in range(tries):
+        cand = torch.cuda.Stream(device)
+        first = first or cand
+        torch.cuda.synchronize(device)
+        busy, done = torch.cuda.Event(), torch.cuda.Event()
+        for _ in range(40):
+            big.fill_(1.0)
+        busy.record(main)
+        with torch.cuda.stream(cand):
+            tiny.add_(1.0)
+            done.record(cand)
+        done.synchronize()
+        concurrent = not busy.query()      # the candidate's kernel finished while the launch stream still had work
+        torch.cuda.synchronize(device)
+        if concurrent:
+            return cand, True
+    return first, False
+
+
 class Engine:
     def __init__(self, model, B, H, W, device, grad_scale=256.0, precision="fp16"):
         """`precision`: "fp16" -- fp16 MFMA operands everywhere (the throughput mode); "fp16x3" -- every conv block
@@ -370,6 +397,26 @@ class Engine:
             raise NotImplementedError("parameters outside the conv blocks (tail)")
         self.out_shape = (B, self.layers[-1].cout, self.layers[-1].H, self.layers[-1].W)
 
+    # ------------------------------------------------------------------ second stream
+    _SIDE_STREAMS = {}      # device index -> (stream, concurrent?)  one per process: every engine of a device shares it
+
+    def _get_side_stream(self):
+        """The second HIP stream (weight gradients, fold + re-pack) -- one that really runs BESIDE the launch stream.
+        HIP multiplexes its streams onto a few hardware queues (4 by default) in creation order, and a stream that lands
+        on the launch stream's queue is silently serialised behind it: with a process group alive (RCCL creates streams
+        of its own first) exactly that happened -- rocprofv3 showed every kernel of both streams on one queue id and the
+        step went from 9.7 to 10.7 ms (profiles/r02c_*).  So candidates are probed: a few milliseconds of work are queued
+        on the launch stream, one tiny kernel on the candidate; the candidate is concurrent if its kernel is done while
+        the launch stream is still busy.  The first concurrent candidate of up to eight is kept for the process."""
+        key = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        if self._side_stream is None:
+            hit = Engine._SIDE_STREAMS.get(key)
+            if hit is None:
+                hit = _probe_side_stream(self.device)
+                Engine._SIDE_STREAMS[key] = hit
+            self._side_stream = hit[0]
+        return self._side_stream
+
     # ------------------------------------------------------------------ per-kernel timing
     def _timed(self, tag, lay, fn, *args, **kw):
         """Run one library call; when profiling, bracket it with HIP events on the launch stream."""
@@ -456,9 +503,7 @@ class Engine:
         if (training and self.overlap_wgrad and self.events is None and self.layers[0].fused_stem
                 and (want == "1" or (want == "auto" and any(lay.fold is not None for lay in self.layers)))):
             main = torch.cuda.current_stream(self.device)
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(self.device)
-            side = self._side_stream
+            side = self._get_side_stream()
             side.wait_stream(main)            # the optimizer step that produced these weights
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
             folds = [lay for lay in self.layers if lay.fold is not None]
@@ -771,17 +816,58 @@ class Engine:
         side = main = None
         if self.overlap_wgrad and self.events is None:    # per-kernel timing: one stream, no overlapping launches
             main = torch.cuda.current_stream(self.device)
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(self.device)
-            side = self._side_stream
+            side = self._get_side_stream()
             flat.record_stream(side)
             # the side stream's split-K slabs must not alias the main stream's: with filter compaction the gather
             # layers run their weight gradient on the main stream while a side-stream one may still be in flight
             if self._side_ws is None or self._side_ws.numel() < self.wgrad_ws.numel():
                 self._side_ws = torch.empty(self.wgrad_ws.numel(), dtype=torch.uint8, device=self.device)
                 self._side_ws.record_stream(side)
+        def fence():
+            """Stream context in which a collective over final slices may be enqueued: this block's slice is written from
+            both streams (dgamma / dbeta and the gather layers' dW on the main one, dW on the side one), so the side stream
+            first waits for everything the main stream has issued so far.  Called by the reducer only when it really
+            launches a bucket (six times per dense step); entering it for every block cost 0.55 ms per step in the one-rank
+            RCCL rehearsal (10.51 -> 9.96 ms)."""
+            ev2 = torch.cuda.Event()
+            ev2.record(main)
+            side.wait_event(ev2)
+            return torch.cuda.stream(side)
+
+        def ready(lay):
+            if on_ready is None:
+                return
+            if side is None:
+                on_ready(flat, lay.p_lo, lay.p_hi)
+            elif getattr(on_ready, "takes_fence", False):
+                on_ready(flat, lay.p_lo, lay.p_hi, fence)
+            else:
+                with fence():
+                    on_ready(flat, lay.p_lo, lay.p_hi)
+
+        # Weight gradients go to the second stream in groups of `chunk` blocks (MCAMD_WGRAD_CHUNK, default 1 = each block
+        # at once).  Every hand-over is an event record in the launch stream's queue plus a cross-queue wait; grouping 2-3
+        # blocks per hand-over measured the same (9.63 / 9.64 / 9.64 ms per dense step), 4 and 6 slower (9.71 / 9.75: the
+        # late start costs more overlap than the saved events).  dY and the block inputs stay in place until the next
+        # forward, so a late start is safe.
+        pending, chunk = [], max(1, int(os.environ.get("MCAMD_WGRAD_CHUNK", "1")))
+
+        def flush():
+            if not pending:
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                for fn, _ in pending:
+                    fn(self._side_ws)
+            for _, l in pending:
+                ready(l)
+            pending.clear()
+
         for lay in reversed(self.layers):
             if lay.fused_stem:
+                flush()
                 # the whole backward of the first block in one pass over the image and G (conv_stem_block.hip)
                 cons = self.consumer_of[lay.out_id]
                 mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
@@ -789,15 +875,7 @@ class Engine:
                             lay.bn.weight.data, lay.scale, lay.shift, lay.mean, lay.invstd, lay.slope, cons.gin, cons.tin.ld,
                             lay.out_t.choff, gmap[id(lay.conv.weight)], gmap[id(lay.bn.weight)], gmap[id(lay.bn.bias)],
                             lay.stem_ws, mask=mask, grad_scale=D)
-                if on_ready is not None:
-                    if side is None:
-                        on_ready(flat, lay.p_lo, lay.p_hi)
-                    else:
-                        ev2 = torch.cuda.Event()
-                        ev2.record(main)
-                        side.wait_event(ev2)
-                        with torch.cuda.stream(side):
-                            on_ready(flat, lay.p_lo, lay.p_hi)
+                ready(lay)
                 continue
             if lay.is_last:
                 ops.nchw_to_padded(grad_out.detach().contiguous().float(), lay.dy, lay.cout_p, 0, S, overflow=self.overflow)
@@ -812,7 +890,7 @@ class Engine:
                                       gmap[id(lay.bn.weight)], gmap[id(lay.bn.bias)], D)
             mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
             dbias = gmap[id(lay.conv.bias)] if lay.conv.bias is not None else None
-            def wgrad_of(ws):
+            def wgrad_of(ws, lay=lay, mask=mask, dbias=dbias):
                 """This block's weight gradient (nothing in the backward chain depends on it)."""
                 if lay.fold is not None:
                     # kept input channels + the ones-channel: dense augmented gradient, then back to OIHW (the folded
@@ -839,30 +917,18 @@ class Engine:
 
             if side is None:
                 wgrad_of(self.wgrad_ws)
+                ready(lay)
             else:
                 # dY of this block is complete on the main stream: the weight gradient runs beside the dgrad /
                 # BatchNorm-backward chain on the second stream (own split-K workspace) and fills its tails
-                ev = torch.cuda.Event()
-                ev.record(main)
-                side.wait_event(ev)
-                with torch.cuda.stream(side):
-                    wgrad_of(self._side_ws)
-            if on_ready is not None:
-                if side is None:
-                    on_ready(flat, lay.p_lo, lay.p_hi)
-                else:
-                    # this block's slice is written from both streams (dgamma / dbeta and the gather layers' dW on the
-                    # main one, dW on the side one): the collective is enqueued from the side stream once it has also
-                    # seen everything the main stream has issued so far
-                    ev2 = torch.cuda.Event()
-                    ev2.record(main)
-                    side.wait_event(ev2)
-                    with torch.cuda.stream(side):
-                        on_ready(flat, lay.p_lo, lay.p_hi)
+                pending.append((wgrad_of, lay))
+                if len(pending) >= chunk or lay.li <= 1:
+                    flush()
             if lay.li > 0:
                 # gradient wrt this block's input slice, written into gin at the slice's channel offset
                 self._timed('dgrad', lay, ops.conv_dgrad_raw, lay.geom_act, lay.dy, lay.cout_p, 0, lay.wd, lay.gin, lay.tin.ld,
                             lay.tin.choff, overflow=self.overflow)
         if side is not None:
+            flush()
             main.wait_stream(side)
         return flat, views
