@@ -358,9 +358,10 @@ static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot, bool raw_epi
             // K >= 1152 for any layer.  (3x3 layers from K = 576, MCAMD_PP_MINK=512, looked like a gain at first -- conv3/5
             // forward 0.183 -> 0.176 ms in one run -- but measured back to back on one box the whole step is 0.5 % slower with
             // it: 9.846 / 9.836 vs 9.800 / 9.782 ms, conv3/5 forward 0.186 vs 0.174 ms in the event pass.)
-            // 1x1 layers from K = 512 (conv10/12 forward 37 -> 32 us, conv15/17 dgrad 30 -> 25 us; K = 256 and the K = 576
-            // 3x3 layers measured equal or slower)
-            if (pp == 1 && (ktot >= 1152 || (ktot == cin_tap && ktot >= env_int("MCAMD_PP_MINK_1X1", 512)) ||
+            // (MCAMD_PP_MINK_1X1=512 sends the 1x1 layers with K >= 512 here too: conv10/12 forward 37 -> 32 us, conv15/17
+            // dgrad 30 -> 25 us, 20 us = 0.2 % of a step in all; K = 256 and the K = 576 3x3 layers measured equal or
+            // slower.  Off by default: these 30 us launches are latency-bound whatever the tile.)
+            if (pp == 1 && (ktot >= 1152 || (ktot == cin_tap && ktot >= env_int("MCAMD_PP_MINK_1X1", 1152)) ||
                             (ktot >= env_int("MCAMD_PP_MINK", 1152) && ktot == 9 * cin_tap))) {
                 // Measured (profiles/): per busy CU the ping-pong tile is ~1.27x the 192x128 tile, but
                 // it runs ONE workgroup per CU, so it only pays when its tiles fill the 256 CUs well: 256 or 192 rows,
