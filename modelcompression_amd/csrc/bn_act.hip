@@ -395,6 +395,173 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(ActBwdArgs a) {
     }
 }
 
+// MaxPool blocks (conv2 / conv5 / conv8 / conv13 of YOLOv2: 0.7 of the 1.5 ms of BatchNorm backward).
+// The generic kernel above spends ~1 300 instructions per item there (SQ_ACTIVE_INST_ANY 0.62 of the wave cycles, 3.6 TB/s:
+// it is issue-bound, not HBM-bound) because it treats the four window pixels as four full backward elements.  Only the
+// argmax pixel receives a gradient, so with  out = dm (g_z - c1 - xhat c2),  xhat = (y - mu) is:
+//     out_k = [k == arg] dm g_z  -  (Bc y_k + A),      Bc = dm c2 is,  A = dm c1 - Bc mu     (per channel, hoisted)
+// i.e. one multiply-add per non-argmax element; the sums of pass 0 need the argmax element only.  The argmax itself is
+// taken exactly as the generic kernel takes it (first maximum of the activations AS STORED by the forward pass, compared
+// as fp16 values here instead of converting them back).  32-bit positions stepped incrementally (no division in the loop).
+// G2: a second gradient at full resolution (the route that reads conv13 beside its pool) is added to every window pixel,
+// so every pixel has a g_z -- still without the generic kernel's per-pixel xhat / select chains.
+template <int PHASE, bool Y32, bool G2>
+__global__ __launch_bounds__(256) void bn_pool_bwd_kernel(ActBwdArgs a) {
+    const int CH = a.C >> 3, lg = __ffs(CH) - 1;        // C / 8 is a power of two (check_c)
+    const int c8 = (threadIdx.x & (CH - 1)) * 8;
+    float sc[8], sh[8], mu[8], is[8], A[8], Bc[8], dm[8];
+    loadf8(a.scale + c8, sc);
+    loadf8(a.shift + c8, sh);
+    loadf8(a.mean + c8, mu);
+    loadf8(a.invstd + c8, is);
+    if (PHASE == 1) {
+        float c1[8], c2[8];
+        loadf8(a.coef + c8, c1);
+        loadf8(a.coef + a.C + c8, c2);
+        if (a.dy_keep) {
+            float kp[8];
+            loadf8(a.dy_keep + c8, kp);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dm[i] = kp[i] != 0.f ? sc[i] : 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dm[i] = sc[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            Bc[i] = dm[i] * c2[i] * is[i];
+            A[i] = dm[i] * c1[i] - Bc[i] * mu[i];
+        }
+    }
+    float sb[8], sg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sb[i] = sg[i] = 0.f;
+    float satmax = 0.f;
+    const int Ho = a.H >> 1, Wo = a.W >> 1, HoWo = Ho * Wo;
+    const unsigned npix = (unsigned)(a.items >> lg);                       // pooled pixels
+    const unsigned stride = (gridDim.x * 256u) >> lg;                      // pooled pixels per grid stride
+    unsigned pix = (blockIdx.x * 256u + threadIdx.x) >> lg;
+    // (b, ho, wo) of `pix` and of the stride, advanced with carries
+    int b = (int)(pix / (unsigned)HoWo), rem = (int)(pix - (unsigned)b * (unsigned)HoWo);
+    int ho = rem / Wo, wo = rem - ho * Wo;
+    const int sb_ = (int)(stride / (unsigned)HoWo), srem = (int)(stride - (unsigned)sb_ * (unsigned)HoWo);
+    const int sho = srem / Wo, swo = srem - sho * Wo;
+    const long long yrow = (long long)a.W * a.y_ld;                         // elements per image row of y
+    for (; pix < npix; pix += stride) {
+        const half_t* yp = (const half_t*)a.y;
+        const long long y0 = (((long long)b * a.H + 2 * ho) * a.W + 2 * wo) * a.y_ld + a.y_choff + c8;
+        float yv[4][8], gv[8];
+        if (Y32) {
+            const float* yf = (const float*)a.y;
+            loadf8(yf + y0, yv[0]);
+            loadf8(yf + y0 + a.y_ld, yv[1]);
+            loadf8(yf + y0 + yrow, yv[2]);
+            loadf8(yf + y0 + yrow + a.y_ld, yv[3]);
+        } else {
+            load8(yp + y0, yv[0]);
+            load8(yp + y0 + a.y_ld, yv[1]);
+            load8(yp + y0 + yrow, yv[2]);
+            load8(yp + y0 + yrow + a.y_ld, yv[3]);
+        }
+        load8(a.g + (long long)pix * a.g_ld + a.g_choff + c8, gv);
+        float g2v[G2 ? 4 : 1][8];
+        if (G2) {
+            const half_t* q0 = a.g2 + (((long long)b * a.H + 2 * ho) * a.W + 2 * wo) * a.g2_ld + a.g2_choff + c8;
+            const long long g2row = (long long)a.W * a.g2_ld;
+            load8(q0, g2v[0]);
+            load8(q0 + a.g2_ld, g2v[G2 ? 1 : 0]);
+            load8(q0 + g2row, g2v[G2 ? 2 : 0]);
+            load8(q0 + g2row + a.g2_ld, g2v[G2 ? 3 : 0]);
+        }
+        float out[4][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float z[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) z[k] = yv[k][i] * sc[i] + sh[i];
+            // first maximum in (h, w) scan order of the activations as the forward pass stored them
+            int arg = 0;
+            float zs = z[0], ys = yv[0][i];
+            if (Y32) {
+                float best = z[0] > 0.f ? z[0] : z[0] * a.slope;
+#pragma unroll
+                for (int k = 1; k < 4; ++k) {
+                    const float av = z[k] > 0.f ? z[k] : z[k] * a.slope;
+                    const bool gt = av > best;
+                    best = gt ? av : best, arg = gt ? k : arg, zs = gt ? z[k] : zs, ys = gt ? yv[k][i] : ys;
+                }
+            } else {
+                half_t best = (half_t)(z[0] > 0.f ? z[0] : z[0] * a.slope);
+#pragma unroll
+                for (int k = 1; k < 4; ++k) {
+                    const half_t av = (half_t)(z[k] > 0.f ? z[k] : z[k] * a.slope);
+                    const bool gt = av > best;
+                    best = gt ? av : best, arg = gt ? k : arg, zs = gt ? z[k] : zs, ys = gt ? yv[k][i] : ys;
+                }
+            }
+            if (G2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float ga = (k == arg ? gv[i] : 0.f) + g2v[G2 ? k : 0][i];
+                    const float gzk = z[k] > 0.f ? ga : ga * a.slope;
+                    if (PHASE == 0) {
+                        sb[i] += gzk;
+                        sg[i] += gzk * ((yv[k][i] - mu[i]) * is[i]);
+                    } else {
+                        const float o = dm[i] * gzk - (Bc[i] * yv[k][i] + A[i]);
+                        out[k][i] = o;
+                        satmax = fmaxf(satmax, fabsf(o));
+                    }
+                }
+            } else {
+                const float gz = zs > 0.f ? gv[i] : gv[i] * a.slope;
+                if (PHASE == 0) {
+                    sb[i] += gz;
+                    sg[i] += gz * ((ys - mu[i]) * is[i]);
+                } else {
+                    const float t = dm[i] * gz;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float o = (k == arg ? t : 0.f) - (Bc[i] * yv[k][i] + A[i]);
+                        out[k][i] = o;
+                        satmax = fmaxf(satmax, fabsf(o));
+                    }
+                }
+            }
+        }
+        if (PHASE == 1) {
+            half_t* d0 = a.dy + pad_off(b, 2 * ho, 2 * wo, a.H, a.W, a.dy_ld) + a.dy_choff + c8;
+            const long long drow = (long long)(a.W + 2) * a.dy_ld;
+            store8(d0, out[0]);
+            store8(d0 + a.dy_ld, out[1]);
+            store8(d0 + drow, out[2]);
+            store8(d0 + drow + a.dy_ld, out[3]);
+        }
+        wo += swo;
+        if (wo >= Wo) wo -= Wo, ++ho;
+        ho += sho;
+        if (ho >= Ho) ho -= Ho, ++b;
+        b += sb_;
+    }
+    if (PHASE == 1 && satmax > 65504.f && a.overflow) atomicOr(a.overflow, 1);
+    if (PHASE == 0) {
+        __shared__ float red[256 * 16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            red[threadIdx.x * 16 + i] = sb[i];
+            red[threadIdx.x * 16 + 8 + i] = sg[i];
+        }
+        __syncthreads();
+        const int reps = 256 / CH;
+        for (int o = threadIdx.x; o < 16 * CH; o += 256) {
+            int ch = o % CH, v = o / CH;
+            float s = 0.f;
+            for (int k = 0; k < reps; ++k) s += red[(k * CH + ch) * 16 + v];
+            a.slab[((long long)blockIdx.x * 2 + (v >> 3)) * a.C + ch * 8 + (v & 7)] = s;
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* slab, int nblocks, int C, double count,
                                                                float inv_scale, float* dgamma, float* dbeta,
                                                                float* coef, const int* perm, int skip_from) {
@@ -617,14 +784,34 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
         BWD_INST(MCAMD_DST_REORG, PHASE);                                                                         \
     else                                                                                                          \
         MCAMD_REQUIRE(false, "bn_act_bwd: bad mode %d", d->mode);
-    BWD_LAUNCH(0)
+    // MaxPool blocks: the argmax form (bn_pool_bwd_kernel); MCAMD_BN_POOL_FAST=0: generic kernel
+    const bool pool_fast_on = !(getenv("MCAMD_BN_POOL_FAST") && atoi(getenv("MCAMD_BN_POOL_FAST")) == 0);
+    const bool pool_fast = pool_fast_on && d->mode == MCAMD_DST_POOL && a.items < (1ll << 31) &&
+                           (unsigned long long)grid * 256ull < (1ull << 31);
+#define POOL_INST(PHASE, Y32_, G2_) hipLaunchKernelGGL((bn_pool_bwd_kernel<PHASE, Y32_, G2_>), dim3(grid), dim3(256), 0, st, a)
+#define POOL_LAUNCH(PHASE)                                                                                        \
+    do {                                                                                                          \
+        if (y32 && d->g2) POOL_INST(PHASE, true, true);                                                           \
+        else if (y32) POOL_INST(PHASE, true, false);                                                              \
+        else if (d->g2) POOL_INST(PHASE, false, true);                                                            \
+        else POOL_INST(PHASE, false, false);                                                                      \
+    } while (0)
+    if (pool_fast) POOL_LAUNCH(0);
+    else {
+        BWD_LAUNCH(0)
+    }
     MCAMD_LAUNCH_CHECK("bn_act_bwd reduce");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((d->C + RED_CPB - 1) / RED_CPB), dim3(1024), 0, st, (const float*)a.slab, grid, d->C,
                        count, 1.0f / d->grad_scale, d->dgamma, d->dbeta, coef, (const int*)d->chan_perm,
                        d->skip_dead_param_grads);
     MCAMD_LAUNCH_CHECK("bn_act_bwd finalize");
-    BWD_LAUNCH(1)
+    if (pool_fast) POOL_LAUNCH(1);
+    else {
+        BWD_LAUNCH(1)
+    }
     MCAMD_LAUNCH_CHECK("bn_act_bwd apply");
+#undef POOL_LAUNCH
+#undef POOL_INST
 #undef BWD_LAUNCH
 #undef BWD_INST
     return MCAMD_OK;

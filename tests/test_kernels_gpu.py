@@ -490,7 +490,10 @@ def _bn_ref(y, gamma, beta, slope, mode, training_stats=True):
     return a, a
 
 
-@pytest.mark.parametrize("mode", [L.DST_PLAIN, L.DST_POOL, L.DST_REORG])
+# mode "pool1": MaxPool with ONE consumer (conv2 / 5 / 8 of YOLOv2: bn_pool_bwd_kernel's argmax-only form); DST_POOL here has
+# the second, full-resolution consumer too (conv13: pooled output + route), its G2 form; MCAMD_BN_POOL_FAST=0 would take
+# the generic kernel for both
+@pytest.mark.parametrize("mode", [L.DST_PLAIN, L.DST_POOL, "pool1", L.DST_REORG])
 @pytest.mark.parametrize("C", [32, 64, 256])
 def test_bn_act_fwd_bwd(dev, mode, C):
     B, H, W = 3, 12, 10
@@ -498,6 +501,8 @@ def test_bn_act_fwd_bwd(dev, mode, C):
     y = q16(torch.randn(B, C, H, W, generator=gen) * 2 + 0.3)
     gamma, beta = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen) * 0.1
     dual = mode == L.DST_POOL
+    if mode == "pool1":
+        mode = L.DST_POOL
     yl = y.clone().requires_grad_(True)
     gl, bl = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     a, out = _bn_ref(yl, gl, bl, 0.1, mode)
@@ -541,6 +546,41 @@ def test_bn_act_fwd_bwd(dev, mode, C):
     assert rel_l2(padded_to_nchw(dy, B, H, W, C, C) / S, yl.grad) < 2e-3
     assert rel_l2(dgamma.cpu(), gl.grad) < TOL and rel_l2(dbeta.cpu(), bl.grad) < TOL
     assert halo_is_zero(dy, B, H, W, C)
+
+
+@pytest.mark.parametrize("dual", [False, True])
+@pytest.mark.parametrize("C,y_ld,keep_n", [(64, 128, 40), (16, 64, 16), (256, 256, 200)])
+def test_bn_pool_bwd_fast_equals_generic(dev, monkeypatch, C, y_ld, keep_n, dual):
+    """bn_pool_bwd_kernel (argmax form of the MaxPool BatchNorm backward) against the generic kernel on the same inputs:
+    a channel slice of a wider y (filter compaction: BatchNorm on the kept channels only), dy_keep zeros, large means."""
+    B, H, W = 3, 20, 12
+    gen = torch.Generator().manual_seed(5 + C)
+    M = B * H * W
+    y = (torch.randn(M, y_ld, generator=gen) * 0.7 + 3.0).half().to(dev)           # mean >> std: the hoisted constants must cope
+    yc = y[:, :C].float()
+    mean = yc.mean(0)
+    invstd = 1.0 / torch.sqrt(yc.var(0, unbiased=False) + 1e-5)
+    gamma = (torch.rand(C, generator=gen) + 0.5).to(dev)
+    beta = (torch.randn(C, generator=gen) * 0.2).to(dev)
+    scale = (gamma * invstd).contiguous()
+    shift = (beta - mean * scale).contiguous()
+    keep = torch.zeros(C, device=dev)
+    keep[:keep_n] = 1.0
+    g = (torch.randn(M // 4, C, generator=gen) * 3).half().to(dev)
+    g2 = (torch.randn(M, C, generator=gen)).half().to(dev) if dual else None
+    res = []
+    for fast in ("0", "1"):
+        monkeypatch.setenv("MCAMD_BN_POOL_FAST", fast)
+        dy = ops.alloc_padded(B, H, W, C, dev)
+        dgm, dbt = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        ops.bn_act_bwd(B, H, W, C, y, y_ld, 0, scale, shift, mean.contiguous(), invstd.contiguous(), 0.1, L.DST_POOL, g, C, 0,
+                       dy, C, 0, dgm, dbt, grad_scale=2.0, g2=g2, g2_ld=C if dual else 0, dy_keep=keep)
+        res.append((dy.float().cpu(), dgm.cpu(), dbt.cpu()))
+    (dy0, dg0, db0), (dy1, dg1, db1) = res
+    assert rel_l2(dg1, dg0) < 1e-5 and rel_l2(db1, db0) < 1e-5
+    assert rel_l2(dy1, dy0) < 2e-4                       # fp16 outputs of two fp32 formulations: rare last-bit differences
+    assert float((dy1 - dy0).abs().max()) <= 2e-3 * float(dy0.abs().max())
+    assert bool((ops.padded_view(dy1.to(dev), B, H, W, C)[:, 1:-1, 1:-1, keep_n:] == 0).all())
 
 
 def test_bn_coeffs_eval(dev):

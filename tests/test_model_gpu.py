@@ -210,7 +210,7 @@ def _teacher_forced(dev, cfg, B, seed, masked, hw=None, only=None, grad_scale=No
         worst[name] = max(worst.get(name, 0.0), val)
         assert val < tol, "%s of conv block %d: %.3e >= %.1e" % (name, lay.index, val, tol)
 
-    dead_expect, dead_idx, folded_producers, nk = {}, {}, {}, {}
+    dead_expect, dead_scale, dead_idx, folded_producers, nk = {}, {}, {}, {}, {}
     for lay in eng.layers:
         if only is not None and lay.li + 1 not in only:
             continue
@@ -411,6 +411,7 @@ def _teacher_forced(dev, cfg, B, seed, masked, hw=None, only=None, grad_scale=No
                 beta = prod.bn.bias.detach().cpu()
                 lp = torch.where(beta[fold_dead] > 0, torch.ones(()), torch.full((), prod.slope))
                 dead_expect[prod.li] = dead_expect.get(prod.li, 0) + (lp * gref[:, fold_dead].double().sum((0, 2, 3))).float()
+                dead_scale[prod.li] = dead_scale.get(prod.li, 0) + (lp * gref[:, fold_dead].double().abs().sum((0, 2, 3))).float()
                 dead_idx[prod.li] = fold_dead
                 c0 = int(lay.in_perm[lay.fold_cin])
                 keepm = torch.ones(gin.shape[1], dtype=torch.bool)
@@ -422,7 +423,14 @@ def _teacher_forced(dev, cfg, B, seed, masked, hw=None, only=None, grad_scale=No
     for li, (prod, deadm) in folded_producers.items():
         if li in dead_expect and all(only is None or c.li + 1 in only for c in prod.fold_consumers):
             got = prod.bn.bias.grad.cpu()[dead_idx[li]]
-            rec("dbeta_folded", rel_l2(got, dead_expect[li]), 2e-3, prod)
+            # A consumer that is a 1x1 layer behind a BatchNorm sees sum_p dY = 0 (the BatchNorm backward removes the mean),
+            # so the true dbeta of its producer's dead channels is ~0: |expect| is 1e-6..1e-7 of sum_p |terms| there (conv3,
+            # 6, 9, 11, 16 of the 40 % model) and a relative error against it compares rounding noise with rounding noise
+            # (3.7e-4 -> 3.2e-3 for conv3 when only the summation order of an upstream kernel changed).  The bound is
+            # therefore relative to the expectation PLUS the fp32 accumulation floor of the cancelling sum.
+            err = float((got - dead_expect[li]).norm())
+            lim = 2e-3 * float(dead_expect[li].norm()) + 1e-7 * float(dead_scale[li].norm())
+            rec("dbeta_folded", 2e-3 * err / lim, 2e-3, prod)
     if folded_producers:
         print("folded producers: %s" % sorted(p.li + 1 for p, _ in folded_producers.values()))
     print("elements within 1e-5 of the LeakyReLU kink taken out of the BatchNorm-backward comparisons: %d" % nk.get("kinks", 0))
