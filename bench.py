@@ -38,6 +38,30 @@ PEAK_HBM_GBS = 8000.0           # HBM3E (MI355X_MICROARCH.md)
 FWD_BWD_GFLOP_PER_IMG = 87.782
 
 
+_JSON_FD = None
+
+
+def claim_stdout():
+    """Only the JSON line may reach stdout.  Libraries print banners there -- RCCL writes a "ROCm version / Hostname /
+    Librccl path" block to stdout when rank 0 creates a communicator -- so file descriptor 1 is pointed at stderr for the
+    whole run and the result goes to the saved descriptor."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        sys.stdout.flush()
+        os.write(_JSON_FD, line)
+
+
 def host_cores():
     return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
@@ -158,7 +182,7 @@ def bench_slim(args, model, dev, rank):
                 res[(name, prec)] = (time.perf_counter() - t0) / args.steps
     if rank == 0:
         t = res[("slim", "fp16")]
-        print(json.dumps({
+        emit({
             "metric": "images/sec (inference forward, 416x416)", "value": round(B / t, 1), "unit": "images/s",
             "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t * 1e3, 3),
             "higher_is_better": True, "dtype": "fp16", "data": "synthetic",
@@ -167,7 +191,7 @@ def bench_slim(args, model, dev, rank):
                        "filters_kept": sum(r[2] for r in rows), "filters_dense": sum(r[1] for r in rows),
                        "masked_dense_images_per_s": round(B / res[("masked_dense", "fp16")], 1),
                        "slim_images_per_s_mixed_precision": round(B / res[("slim", "mixed")], 1),
-                       "masked_dense_images_per_s_mixed_precision": round(B / res[("masked_dense", "mixed")], 1)}}))
+                       "masked_dense_images_per_s_mixed_precision": round(B / res[("masked_dense", "mixed")], 1)}})
 
 
 def bench_prune(args, model, dev):
@@ -251,7 +275,7 @@ def bench_prune(args, model, dev):
                                          "weight_prune %.2f s, quick_filter_prune %.2f s (the reference itself spends "
                                          "25.4 s / 2.9 s, SURVEY section 6: a Python list of 50.6 M scalars)" % (c_w, c_f),
                                "quick_filter_prune_s": round(c_f, 3), "weight_prune_s": round(c_w, 3)}
-    print(json.dumps(res))
+    emit(res)
 
 
 def main():
@@ -274,6 +298,7 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    claim_stdout()
 
     import torch
     import torch.distributed as dist
@@ -468,7 +493,7 @@ def main():
                              "collectives_per_step": reducer.collectives // max(1, args.warmup + args.steps + nprof)}
     elif not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(cpu_batch_for_host(args.cpu_batch), args.cpu_steps)
-    print(json.dumps(res))
+    emit(res)
 
 
 if __name__ == "__main__":
