@@ -395,6 +395,97 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(ActBwdArgs a) {
     }
 }
 
+// PLAIN blocks (16 of YOLOv2's 21 BatchNorm blocks) without a second gradient: the same hoisted form as bn_pool_bwd_kernel
+// below, and no position arithmetic beyond one incremental (b, h, w) for the padded dY address.  The generic kernel's two
+// 64-bit divisions per 48-byte item made its loop 450-640 instructions long; on the 13x13 layers (5 items per thread,
+// 4 waves per SIMD) that is ~17 us of pure instruction issue for a pass that moves 44 MB -- 14.7 us measured against
+// 9 us for the forward pass over the same bytes.
+template <int PHASE, bool Y32>
+__global__ __launch_bounds__(256) void bn_plain_bwd_kernel(ActBwdArgs a) {
+    const int CH = a.C >> 3, lg = __ffs(CH) - 1;        // C / 8 is a power of two (check_c)
+    const int c8 = (threadIdx.x & (CH - 1)) * 8;
+    float sc[8], sh[8], mu[8], is[8], A[8], Bc[8], dm[8];
+    loadf8(a.scale + c8, sc);
+    loadf8(a.shift + c8, sh);
+    loadf8(a.mean + c8, mu);
+    loadf8(a.invstd + c8, is);
+    if (PHASE == 1) {
+        float c1[8], c2[8];
+        loadf8(a.coef + c8, c1);
+        loadf8(a.coef + a.C + c8, c2);
+        if (a.dy_keep) {
+            float kp[8];
+            loadf8(a.dy_keep + c8, kp);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dm[i] = kp[i] != 0.f ? sc[i] : 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dm[i] = sc[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            Bc[i] = dm[i] * c2[i] * is[i];
+            A[i] = dm[i] * c1[i] - Bc[i] * mu[i];
+        }
+    }
+    float sb[8], sg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sb[i] = sg[i] = 0.f;
+    float satmax = 0.f;
+    const int HW = a.H * a.W;
+    const unsigned npix = (unsigned)(a.items >> lg);
+    const unsigned stride = (gridDim.x * 256u) >> lg;                      // pixels per grid stride
+    unsigned pix = (blockIdx.x * 256u + threadIdx.x) >> lg;
+    int b = (int)(pix / (unsigned)HW), rem = (int)(pix - (unsigned)b * (unsigned)HW);
+    int h = rem / a.W, w = rem - h * a.W;
+    const int sb_ = (int)(stride / (unsigned)HW), srem = (int)(stride - (unsigned)sb_ * (unsigned)HW);
+    const int sh_ = srem / a.W, sw_ = srem - sh_ * a.W;
+    for (; pix < npix; pix += stride) {
+        float yv[8], gv[8];
+        load_y<Y32>(a.y, (long long)pix * a.y_ld + a.y_choff + c8, yv);
+        load8(a.g + (long long)pix * a.g_ld + a.g_choff + c8, gv);
+        float out[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float z = yv[i] * sc[i] + sh[i];
+            const float gz = z > 0.f ? gv[i] : gv[i] * a.slope;
+            if (PHASE == 0) {
+                sb[i] += gz;
+                sg[i] += gz * ((yv[i] - mu[i]) * is[i]);
+            } else {
+                const float o = dm[i] * gz - (Bc[i] * yv[i] + A[i]);
+                out[i] = o;
+                satmax = fmaxf(satmax, fabsf(o));
+            }
+        }
+        if (PHASE == 1) {
+            store8(a.dy + pad_off(b, h, w, a.H, a.W, a.dy_ld) + a.dy_choff + c8, out);
+            w += sw_;
+            if (w >= a.W) w -= a.W, ++h;
+            h += sh_;
+            if (h >= a.H) h -= a.H, ++b;
+            b += sb_;
+        }
+    }
+    if (PHASE == 1 && satmax > 65504.f && a.overflow) atomicOr(a.overflow, 1);
+    if (PHASE == 0) {
+        __shared__ float red[256 * 16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            red[threadIdx.x * 16 + i] = sb[i];
+            red[threadIdx.x * 16 + 8 + i] = sg[i];
+        }
+        __syncthreads();
+        const int reps = 256 / CH;
+        for (int o = threadIdx.x; o < 16 * CH; o += 256) {
+            int ch = o % CH, v = o / CH;
+            float s = 0.f;
+            for (int k = 0; k < reps; ++k) s += red[(k * CH + ch) * 16 + v];
+            a.slab[((long long)blockIdx.x * 2 + (v >> 3)) * a.C + ch * 8 + (v & 7)] = s;
+        }
+    }
+}
+
 // MaxPool blocks (conv2 / conv5 / conv8 / conv13 of YOLOv2: 0.7 of the 1.5 ms of BatchNorm backward).
 // The generic kernel above spends ~1 300 instructions per item there (SQ_ACTIVE_INST_ANY 0.62 of the wave cycles, 3.6 TB/s:
 // it is issue-bound, not HBM-bound) because it treats the four window pixels as four full backward elements.  Only the
@@ -796,7 +887,17 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
         else if (d->g2) POOL_INST(PHASE, false, true);                                                            \
         else POOL_INST(PHASE, false, false);                                                                      \
     } while (0)
+    // PLAIN blocks without a second gradient: bn_plain_bwd_kernel (MCAMD_BN_PLAIN_FAST=0: generic kernel)
+    const bool plain_fast = !(getenv("MCAMD_BN_PLAIN_FAST") && atoi(getenv("MCAMD_BN_PLAIN_FAST")) == 0) &&
+                            d->mode == MCAMD_DST_PLAIN && !d->g2 && a.items < (1ll << 31) &&
+                            (unsigned long long)grid * 256ull < (1ull << 31);
+#define PLAIN_LAUNCH(PHASE)                                                                                       \
+    do {                                                                                                          \
+        if (y32) hipLaunchKernelGGL((bn_plain_bwd_kernel<PHASE, true>), dim3(grid), dim3(256), 0, st, a);         \
+        else hipLaunchKernelGGL((bn_plain_bwd_kernel<PHASE, false>), dim3(grid), dim3(256), 0, st, a);            \
+    } while (0)
     if (pool_fast) POOL_LAUNCH(0);
+    else if (plain_fast) PLAIN_LAUNCH(0);
     else {
         BWD_LAUNCH(0)
     }
@@ -806,11 +907,13 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
                        d->skip_dead_param_grads);
     MCAMD_LAUNCH_CHECK("bn_act_bwd finalize");
     if (pool_fast) POOL_LAUNCH(1);
+    else if (plain_fast) PLAIN_LAUNCH(1);
     else {
         BWD_LAUNCH(1)
     }
     MCAMD_LAUNCH_CHECK("bn_act_bwd apply");
 #undef POOL_LAUNCH
+#undef PLAIN_LAUNCH
 #undef POOL_INST
 #undef BWD_LAUNCH
 #undef BWD_INST

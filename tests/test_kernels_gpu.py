@@ -548,12 +548,13 @@ def test_bn_act_fwd_bwd(dev, mode, C):
     assert halo_is_zero(dy, B, H, W, C)
 
 
-@pytest.mark.parametrize("dual", [False, True])
-@pytest.mark.parametrize("C,y_ld,keep_n", [(64, 128, 40), (16, 64, 16), (256, 256, 200)])
-def test_bn_pool_bwd_fast_equals_generic(dev, monkeypatch, C, y_ld, keep_n, dual):
-    """bn_pool_bwd_kernel (argmax form of the MaxPool BatchNorm backward) against the generic kernel on the same inputs:
-    a channel slice of a wider y (filter compaction: BatchNorm on the kept channels only), dy_keep zeros, large means."""
-    B, H, W = 3, 20, 12
+@pytest.mark.parametrize("mode,dual", [(L.DST_POOL, False), (L.DST_POOL, True), (L.DST_PLAIN, False)])
+@pytest.mark.parametrize("C,y_ld,keep_n", [(64, 128, 40), (16, 64, 16), (256, 256, 200), (1024, 1024, 1024)])
+def test_bn_pool_bwd_fast_equals_generic(dev, monkeypatch, C, y_ld, keep_n, mode, dual):
+    """bn_pool_bwd_kernel (argmax form of the MaxPool BatchNorm backward) and bn_plain_bwd_kernel (hoisted form for PLAIN
+    blocks) against the generic kernel on the same inputs: a channel slice of a wider y (filter compaction: BatchNorm on
+    the kept channels only), dy_keep zeros, large means, a grid-stride loop of several items per thread."""
+    B, H, W = (3, 20, 12) if C < 1024 else (9, 26, 26)
     gen = torch.Generator().manual_seed(5 + C)
     M = B * H * W
     y = (torch.randn(M, y_ld, generator=gen) * 0.7 + 3.0).half().to(dev)           # mean >> std: the hoisted constants must cope
@@ -566,14 +567,15 @@ def test_bn_pool_bwd_fast_equals_generic(dev, monkeypatch, C, y_ld, keep_n, dual
     shift = (beta - mean * scale).contiguous()
     keep = torch.zeros(C, device=dev)
     keep[:keep_n] = 1.0
-    g = (torch.randn(M // 4, C, generator=gen) * 3).half().to(dev)
+    g = (torch.randn(M // 4 if mode == L.DST_POOL else M, C, generator=gen) * 3).half().to(dev)
     g2 = (torch.randn(M, C, generator=gen)).half().to(dev) if dual else None
     res = []
     for fast in ("0", "1"):
         monkeypatch.setenv("MCAMD_BN_POOL_FAST", fast)
+        monkeypatch.setenv("MCAMD_BN_PLAIN_FAST", fast)
         dy = ops.alloc_padded(B, H, W, C, dev)
         dgm, dbt = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
-        ops.bn_act_bwd(B, H, W, C, y, y_ld, 0, scale, shift, mean.contiguous(), invstd.contiguous(), 0.1, L.DST_POOL, g, C, 0,
+        ops.bn_act_bwd(B, H, W, C, y, y_ld, 0, scale, shift, mean.contiguous(), invstd.contiguous(), 0.1, mode, g, C, 0,
                        dy, C, 0, dgm, dbt, grad_scale=2.0, g2=g2, g2_ld=C if dual else 0, dy_keep=keep)
         res.append((dy.float().cpu(), dgm.cpu(), dbt.cpu()))
     (dy0, dg0, db0), (dy1, dg1, db1) = res
