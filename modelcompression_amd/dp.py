@@ -174,6 +174,11 @@ class GradReducer:
         inv = 1.0 / self.fp16_scale if self.transport == "fp16" else 1.0
 
         def done(src=src, idx=idx, lo=lo, hi=hi, inv=inv):
+            if src.is_cuda:
+                # `src` was allocated in the stream context the bucket was launched from (the engine's second stream) and is
+                # read here on the stream that waited for the collective: tell the caching allocator, or the block could be
+                # handed out again on the second stream while this copy is still queued
+                src.record_stream(torch.cuda.current_stream(src.device))
             vals = src.to(torch.float32) * inv if self.transport == "fp16" else src
             if idx is not None:
                 flat.index_copy_(0, idx, vals)
