@@ -801,7 +801,9 @@ class Engine:
 
     def backward(self, grad_out, on_ready=None):
         """grad wrt the returned logits -> one flat fp32 gradient buffer; returns per-parameter views.
-        `on_ready(flat, lo, hi)` is called as soon as every kernel writing flat[lo:hi] is enqueued
+        `on_ready(flat, lo, hi)` -- or `on_ready(flat, lo, hi, fence)` when the callable has `takes_fence = True`:
+        `fence()` returns the stream context in which that slice is visible, to be entered only when a collective is
+        really launched -- is called as soon as every kernel writing flat[lo:hi] is enqueued
         (layers finish last-to-first, so the slices walk down from the tail): dp.GradReducer
         starts its all-reduce buckets there."""
         S = self.grad_scale

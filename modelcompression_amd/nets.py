@@ -249,7 +249,7 @@ class Darknet(nn.Module):
         self._engines = {}
         self._weights_dirty = True
         self._grad_hook = None          # callable(flat_grad) run at the end of backward (data parallel)
-        self._grad_ready_hook = None    # callable(flat_grad, lo, hi): that slice is final (overlapped all-reduce)
+        self._grad_ready_hook = None    # callable(flat_grad, lo, hi[, fence]): that slice is final (overlapped all-reduce; Engine.backward)
         self._last_flat_grad = None
         self.grad_scale = 256.0         # fp16 gradient scaling inside the engine, undone in fp32
         # Operand precision of the forward convolutions (engine.py): "fp16" (throughput), "fp16x3" (split hi/lo
