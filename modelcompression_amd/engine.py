@@ -836,13 +836,23 @@ class Engine:
             side.wait_event(ev2)
             return torch.cuda.stream(side)
 
+        def on_side():
+            """The same context WITHOUT a new event: enough for every block whose weight gradient was handed to the second
+            stream, because that hand-over already made the second stream wait for an event recorded on the launch stream
+            BEHIND the block's BatchNorm backward -- the only launch-stream kernels that write into the block's slice
+            (dgamma / dbeta; everything else, dW, dbias, the unfolded columns and dbeta of folded producers, is written by
+            the second stream itself).  Saves the six event records per step the bucket launches put into the launch
+            stream's queue."""
+            return torch.cuda.stream(side)
+
         def ready(lay):
             if on_ready is None:
                 return
             if side is None:
                 on_ready(flat, lay.p_lo, lay.p_hi)
             elif getattr(on_ready, "takes_fence", False):
-                on_ready(flat, lay.p_lo, lay.p_hi, fence)
+                # (the fused first block writes its whole slice on the launch stream: it needs the real fence)
+                on_ready(flat, lay.p_lo, lay.p_hi, fence if lay.fused_stem else on_side)
             else:
                 with fence():
                     on_ready(flat, lay.p_lo, lay.p_hi)
