@@ -442,8 +442,7 @@ def main():
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
-            want = {9: "void igemm9_kernel", 2: "void igemm_pp_kernel<0, %d," % dom_tile[0]}.get(
-                dom_tile[3], "void igemm_kernel<%d, %d," % dom_tile[:2])
+            want = {2: "void igemm_pp_kernel<0, %d," % dom_tile[0]}.get(dom_tile[3], "void igemm_kernel<%d, %d," % dom_tile[:2])
             if tj["kernel"].startswith(want):
                 traffic = round(tj["hbm_bytes_per_launch"])
         except Exception:
@@ -477,8 +476,7 @@ def main():
         "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
                      "algorithmic_gflop_per_launch": round(dom_flop / max(dom_n, 1) / 1e9, 2),
-                     "kernel": ("igemm9_kernel<0> 128x128x64 padded-pixel 9-tap (conv fwd + dgrad launches)" if dom_tile[3] == 9 else
-                                "igemm_pp_kernel<0,%d,%d,16> %dx%dx%d ping-pong (conv fwd + dgrad launches of that instance)" % (
+                     "kernel": ("igemm_pp_kernel<0,%d,%d,16> %dx%dx%d ping-pong (conv fwd + dgrad launches of that instance)" % (
                                     dom_tile[:2] + dom_tile[:3]) if dom_tile[3] == 2 else
                                 "igemm_kernel<%d,%d,..,%d,2,0> (conv fwd + dgrad launches of that instance)" % dom_tile[:3]),
                      "launches_per_step": dom_n // nprof,

@@ -46,6 +46,9 @@ extern "C" {
 #define MCAMD_EWORKSPACE (-3) /* workspace too small */
 
 int mcamd_version(void);              /* 100*major + minor */
+/* The MCAMD_* tuning switches are read from the environment once per process, at their first
+ * use -- never per launch.  A process that changes one afterwards (tests, A/B runs) calls this to have them re-read. */
+void mcamd_reload_config(void);
 const char* mcamd_arch(void);         /* "gfx950" */
 const char* mcamd_last_error(void);   /* per-thread, never NULL */
 
@@ -98,7 +101,7 @@ int32_t mcamd_conv_stats_rows(const mcamd_conv_geom* g);
 int32_t mcamd_conv_stats_rows_mode(const mcamd_conv_geom* g, int32_t mode);
 
 /* Workgroup tile {BM, BN, BK, kernel} the forward (dgrad == 0) or dgrad launch of this geometry uses:
- * kernel 0 = igemm_kernel<BM,BN,..,BK,..> (one tap per K chunk), 9 = igemm9_kernel (padded-pixel 9-tap),
+ * kernel 0 = igemm_kernel<BM,BN,..,BK,..> (one tap per K chunk),
  * 2 = igemm_pp_kernel (ping-pong, one workgroup per CU), 1 = stem_fwd_kernel (first layer, no LDS staging),
  * 4 = small3x3_kernel (narrow 3x3 layers on huge images, no LDS staging). */
 int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int32_t out[4]);

@@ -93,6 +93,7 @@ SIGNATURES = {
     "mcamd_version": (C.c_int, []),
     "mcamd_arch": (C.c_char_p, []),
     "mcamd_last_error": (C.c_char_p, []),
+    "mcamd_reload_config": (None, []),
     "mcamd_conv_stats_rows": (_I32, [C.POINTER(ConvGeom)]),
     "mcamd_conv_stats_rows_mode": (_I32, [C.POINTER(ConvGeom), _I32]),
     "mcamd_conv_tile_info": (C.c_int, [C.POINTER(ConvGeom), _I32, C.POINTER(_I32)]),
@@ -149,6 +150,11 @@ def lib():
             fn.argtypes = args
         _lib = h
     return _lib
+
+
+def reload_config():
+    """Have the library re-read its MCAMD_* switches (they are cached at first use; tests that change one call this)."""
+    lib().mcamd_reload_config()
 
 
 def check(rc, what=""):

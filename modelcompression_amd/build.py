@@ -20,7 +20,6 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno
 SOURCES = {
     "api.hip": [],
     "conv_igemm.hip": [],
-    "conv_igemm9.hip": [],
     "conv_igemm_pp.hip": [],
     "conv_stem.hip": [],
     "conv_stem_block.hip": [],

@@ -1,6 +1,7 @@
 // C-ABI entry points of libmcamd.so (see include/mcamd.h): argument validation, geometry ->
 // launch descriptors, weight packing.  No allocation, no synchronisation.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "kernels.h"
@@ -14,7 +15,20 @@ void mcamd_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int mcamd_version(void) { return 100; }
+int g_mcamd_env_generation = 0;
+int McamdEnvSlot::get(const char* name, int dflt) {
+    const int g = __atomic_load_n(&g_mcamd_env_generation, __ATOMIC_ACQUIRE);
+    if (gen != g) {       // (a race between host threads re-reads the same variable twice: harmless)
+        const char* s = getenv(name);
+        has = s && *s ? 1 : 0;
+        val = has ? atoi(s) : 0;
+        __atomic_store_n(&gen, g, __ATOMIC_RELEASE);
+    }
+    return has ? val : dflt;
+}
+extern "C" void mcamd_reload_config(void) { __atomic_add_fetch(&g_mcamd_env_generation, 1, __ATOMIC_ACQ_REL); }
+
+extern "C" int mcamd_version(void) { return 101; }
 extern "C" const char* mcamd_arch(void) { return "gfx950"; }
 extern "C" const char* mcamd_last_error(void) { return g_err; }
 
@@ -339,8 +353,6 @@ static int fill_epilogue(IgemmArgs& a, const mcamd_conv_epilogue* e, int n_out, 
 extern "C" int32_t mcamd_conv_stats_rows(const mcamd_conv_geom* g) {
     if (!g) return 0;
     if (mcamd_stem_direct_ok(g->stem, g->cout, MCAMD_EPI_RAW_F16)) return mcamd_stem_rows((long long)g->B * g->H * g->W);
-    if (mcamd_igemm9_ok(g->ksize, g->stem, g->cout, cin_tap_of(g), g->W, MCAMD_EPI_RAW_F16))
-        return mcamd_igemm9_rows((long long)g->B * (g->H + 2) * (g->W + 2), g->cout);
     return mcamd_igemm_rows((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g), ntaps_of(g) * cin_tap_of(g));
 }
 
@@ -359,11 +371,6 @@ extern "C" int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int
         out[0] = 32, out[1] = g->cout, out[2] = 48, out[3] = 1;   // stem_fwd_kernel (conv_stem.hip)
         return MCAMD_OK;
     }
-    if (mcamd_igemm9_ok(g->ksize, g->stem, dgrad ? g->cin : g->cout, dgrad ? cout_p_of(g) : cin_tap_of(g), g->W,
-                        MCAMD_EPI_RAW_F16)) {
-        out[0] = 128, out[1] = 128, out[2] = 64, out[3] = 9;   // igemm9_kernel (padded-pixel 9-tap)
-        return MCAMD_OK;
-    }
     if (dgrad && mcamd_win3x3_shape((long long)g->B * g->H * g->W, g->cin, cout_p_of(g), g->ksize * g->ksize * cout_p_of(g), g->W)) {
         out[0] = 32, out[1] = round_up_int(g->cin, 16), out[2] = 64, out[3] = 5;   // win3x3_kernel (conv_win.hip)
         return MCAMD_OK;
@@ -371,29 +378,6 @@ extern "C" int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int
     mcamd_igemm_tile((long long)g->B * g->H * g->W, dgrad ? g->cin : g->cout, dgrad ? cout_p_of(g) : cin_tap_of(g),
                      dgrad ? g->ksize * g->ksize * cout_p_of(g) : ntaps_of(g) * cin_tap_of(g), out);
     return MCAMD_OK;
-}
-
-// 3x3 layers on small images go through the padded-pixel 9-tap kernel (conv_igemm9.hip)
-static int launch_igemm9(const IgemmArgs& a, const mcamd_conv_geom* g, hipStream_t st) {
-    Igemm9Args q;
-    memset(&q, 0, sizeof(q));
-    q.x = a.x;
-    q.w = a.w;
-    q.y = a.y;
-    q.stats = a.stats;
-    q.scale = a.scale;
-    q.shift = a.shift;
-    q.x_ld = a.x_ld;
-    q.x_off = a.x_off;
-    q.H = g->H, q.W = g->W, q.W2 = g->W + 2, q.HW2 = (g->H + 2) * (g->W + 2);
-    q.S = mcamd_igemm9_S(g->W);
-    q.P = g->B * q.HW2;
-    q.N = a.N;
-    q.ktot = a.ktot;
-    q.cin_tap = a.cin_tap;
-    q.mode = a.mode, q.y_ld = a.y_ld, q.y_choff = a.y_choff, q.stats_ld = a.stats_ld;
-    q.slope = a.slope;
-    return mcamd_igemm9_launch(q, st);
 }
 
 extern "C" int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const void* wp_fwd, const mcamd_conv_epilogue* epi,
@@ -416,11 +400,8 @@ extern "C" int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const voi
     a.kb = kblock_of(a.cin_tap);
     a.ktot = a.ntaps * a.cin_tap;
     fill_taps(g->ksize, g->stem, a.x_row_stride, g->x_ld, a.tap_off);
-    const bool nine = epi && mcamd_igemm9_ok(g->ksize, g->stem, g->cout, a.cin_tap, g->W, epi->mode);
     const bool stem_direct = epi && mcamd_stem_direct_ok(g->stem, g->cout, epi->mode);
-    if (fill_epilogue(a, epi, g->cout, a.M, a.cin_tap, a.ktot, "conv_fwd",
-                      stem_direct ? mcamd_stem_rows(a.M)
-                                  : (nine ? mcamd_igemm9_rows((long long)g->B * (g->H + 2) * (g->W + 2), g->cout) : -1)))
+    if (fill_epilogue(a, epi, g->cout, a.M, a.cin_tap, a.ktot, "conv_fwd", stem_direct ? mcamd_stem_rows(a.M) : -1))
         return MCAMD_EINVAL;
     if (stem_direct) {       // conv_stem.hip: weights in registers, image fragments straight from global memory
         StemArgs q;
@@ -429,7 +410,6 @@ extern "C" int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const voi
         q.H = g->H, q.W = g->W, q.HW = a.HW, q.M = a.M;
         return mcamd_stem_launch(q, g->cout, (hipStream_t)stream);
     }
-    if (nine) return launch_igemm9(a, g, (hipStream_t)stream);
     return mcamd_igemm_launch(a, (hipStream_t)stream);
 }
 
@@ -459,7 +439,6 @@ extern "C" int mcamd_conv_dgrad(const mcamd_conv_geom* g, const void* dy, int32_
     fill_taps(g->ksize, 0, a.x_row_stride, dy_ld, a.tap_off);
     MCAMD_REQUIRE(epi && epi->mode != MCAMD_EPI_PAD_F16 && !epi->stats, "conv_dgrad: epilogue must be mode 0 (no stats) or 1");
     if (fill_epilogue(a, epi, g->cin, a.M, a.cin_tap, a.ktot, "conv_dgrad")) return MCAMD_EINVAL;
-    if (mcamd_igemm9_ok(g->ksize, 0, g->cin, a.cin_tap, g->W, epi->mode)) return launch_igemm9(a, g, (hipStream_t)stream);
     return mcamd_igemm_launch(a, (hipStream_t)stream);
 }
 

@@ -876,7 +876,7 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
     else                                                                                                          \
         MCAMD_REQUIRE(false, "bn_act_bwd: bad mode %d", d->mode);
     // MaxPool blocks: the argmax form (bn_pool_bwd_kernel); MCAMD_BN_POOL_FAST=0: generic kernel
-    const bool pool_fast_on = !(getenv("MCAMD_BN_POOL_FAST") && atoi(getenv("MCAMD_BN_POOL_FAST")) == 0);
+    const bool pool_fast_on = MCAMD_ENV_INT("MCAMD_BN_POOL_FAST", 1) != 0;
     const bool pool_fast = pool_fast_on && d->mode == MCAMD_DST_POOL && a.items < (1ll << 31) &&
                            (unsigned long long)grid * 256ull < (1ull << 31);
 #define POOL_INST(PHASE, Y32_, G2_) hipLaunchKernelGGL((bn_pool_bwd_kernel<PHASE, Y32_, G2_>), dim3(grid), dim3(256), 0, st, a)
@@ -888,7 +888,7 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
         else POOL_INST(PHASE, false, false);                                                                      \
     } while (0)
     // PLAIN blocks without a second gradient: bn_plain_bwd_kernel (MCAMD_BN_PLAIN_FAST=0: generic kernel)
-    const bool plain_fast = !(getenv("MCAMD_BN_PLAIN_FAST") && atoi(getenv("MCAMD_BN_PLAIN_FAST")) == 0) &&
+    const bool plain_fast = MCAMD_ENV_INT("MCAMD_BN_PLAIN_FAST", 1) != 0 &&
                             d->mode == MCAMD_DST_PLAIN && !d->g2 && a.items < (1ll << 31) &&
                             (unsigned long long)grid * 256ull < (1ull << 31);
 #define PLAIN_LAUNCH(PHASE)                                                                                       \

@@ -32,6 +32,16 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 void mcamd_set_error(const char* fmt, ...);
 
+// Tuning switches (MCAMD_* environment variables) are read ONCE per call site, not per launch:
+// MCAMD_ENV_INT caches the value until mcamd_reload_config() bumps the generation (tests and A/B runs that change a
+// switch inside one process call it; a training step never touches the environment).
+extern int g_mcamd_env_generation;
+struct McamdEnvSlot {
+    int gen = -1, has = 0, val = 0;
+    int get(const char* name, int dflt);
+};
+#define MCAMD_ENV_INT(name, dflt) (([]() -> McamdEnvSlot* { static McamdEnvSlot slot_; return &slot_; }())->get(name, dflt))
+
 #define MCAMD_REQUIRE(cond, ...)            \
     do {                                    \
         if (!(cond)) {                      \

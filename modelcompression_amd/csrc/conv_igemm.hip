@@ -333,11 +333,6 @@ struct TileCfg {
     int kind;   // 0: igemm_kernel<...>, 2: igemm_pp_kernel (ping-pong, conv_igemm_pp.hip), 4: small3x3_kernel (conv_small.hip)
 };
 
-static int env_int(const char* name, int dflt) {
-    const char* s = getenv(name);
-    return s && *s ? atoi(s) : dflt;
-}
-
 // Workgroup tile for an implicit GEMM of M pixels x n channels.  The L2->LDS operand stream bounds
 // the kernel (bytes per flop = (1/BM + 1/BN) / 1), so bigger tiles are faster per tile, but the
 // machine has 256 CUs and the late layers have few tiles: pick the candidate with the best
@@ -351,7 +346,7 @@ static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot, bool raw_epi
     }
     // 256x256 ping-pong form (one workgroup per CU).  MCAMD_PP: 0 never, 1 by the cost rule below, 2 whenever legal.
     {
-        const int pp = env_int("MCAMD_PP", 1);
+        const int pp = MCAMD_ENV_INT("MCAMD_PP", 1);
         if (pp && ktot >= 256 && n >= 128 && M >= 256) {
             bool use = pp == 2;
             int bm = 256, bn = 256;
@@ -361,8 +356,8 @@ static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot, bool raw_epi
             // (MCAMD_PP_MINK_1X1=512 sends the 1x1 layers with K >= 512 here too: conv10/12 forward 37 -> 32 us, conv15/17
             // dgrad 30 -> 25 us, 20 us = 0.2 % of a step in all; K = 256 and the K = 576 3x3 layers measured equal or
             // slower.  Off by default: these 30 us launches are latency-bound whatever the tile.)
-            if (pp == 1 && (ktot >= 1152 || (ktot == cin_tap && ktot >= env_int("MCAMD_PP_MINK_1X1", 1152)) ||
-                            (ktot >= env_int("MCAMD_PP_MINK", 1152) && ktot == 9 * cin_tap))) {
+            if (pp == 1 && (ktot >= 1152 || (ktot == cin_tap && ktot >= MCAMD_ENV_INT("MCAMD_PP_MINK_1X1", 1152)) ||
+                            (ktot >= MCAMD_ENV_INT("MCAMD_PP_MINK", 1152) && ktot == 9 * cin_tap))) {
                 // Measured (profiles/): per busy CU the ping-pong tile is ~1.27x the 192x128 tile, but
                 // it runs ONE workgroup per CU, so it only pays when its tiles fill the 256 CUs well: 256 or 192 rows,
                 // 256 or 128 columns (128 columns stage 1.3x the bytes per flop: costed at 0.8 of the 256-column rate),
@@ -382,8 +377,8 @@ static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot, bool raw_epi
                 use = best_cost >= 0;
             }
             if (pp >= 2) {
-                if (env_int("MCAMD_PP_BM", 256) == 192) bm = 192;
-                if (env_int("MCAMD_PP_BN", 256) == 128) bn = 128;
+                if (MCAMD_ENV_INT("MCAMD_PP_BM", 256) == 192) bm = 192;
+                if (MCAMD_ENV_INT("MCAMD_PP_BN", 256) == 128) bn = 128;
             }
             if (use) {
                 t.bm = bm, t.bn = bn, t.bk = 32, t.kind = 2;
@@ -402,22 +397,22 @@ static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot, bool raw_epi
     // Few tiles (the 13x13 layers at the per-GPU batch of BASELINE configs[3], B = 32: M = 5 408 -> 43 x 4 tiles of 128 x 128
     // for N = 512, 172 workgroups on 256 CUs): 64-column tiles double the workgroups at 2/3 of the per-tile rate
     // (dgrad total at B = 32: 1.69 -> 1.65 ms per step, 6.235 -> 6.22 ms per step; nothing changes at B = 64)
-    if (t.bn == 128 && n % 64 == 0 && env_int("MCAMD_NARROW_FILL", 1)) {
+    if (t.bn == 128 && n % 64 == 0 && MCAMD_ENV_INT("MCAMD_NARROW_FILL", 1)) {
         const long long t128 = ((M + 127) / 128) * ((n + 127) / 128);
         if (t128 < 256 && 2 * t128 <= 512) t.bn = 64;
     }
-    int want_bk = env_int("MCAMD_BK", 64);
+    int want_bk = MCAMD_ENV_INT("MCAMD_BK", 64);
     t.bk = (want_bk == 64 && cin_tap % 64 == 0) ? 64 : 32;
     // Tile quantisation: 2 workgroups per CU = 512 slots.  A 192-row tile (wave tile 96x64) often turns
     // a nearly empty last round into none (13x13 layers at B=64: 680 tiles -> 456); time ~ rounds x BM.
-    if (t.bm == 128 && t.bn == 128 && t.bk == 64 && env_int("MCAMD_BM192", 1) &&
-        (ktot >= env_int("MCAMD_BM192_MINK", 2048) || env_int("MCAMD_BM192", 1) == 2)) {   // pays only when the K loop is long
+    if (t.bm == 128 && t.bn == 128 && t.bk == 64 && MCAMD_ENV_INT("MCAMD_BM192", 1) &&
+        (ktot >= MCAMD_ENV_INT("MCAMD_BM192_MINK", 2048) || MCAMD_ENV_INT("MCAMD_BM192", 1) == 2)) {   // pays only when the K loop is long
         const long long nt = (n + 127) / 128;
         const long long t128 = ((M + 127) / 128) * nt, t192 = ((M + 191) / 192) * nt;
         const long long cost128 = ((t128 + 511) / 512) * 128, cost192 = ((t192 + 511) / 512) * 192;
         // ties go to the 192-row tile: fewer, fuller rounds and 20 % less staged bytes per flop (26x26 forward, K = 2304:
         // 0.127 vs 0.134 ms)
-        if (cost192 <= cost128 || env_int("MCAMD_BM192", 1) == 2) t.bm = 192;
+        if (cost192 <= cost128 || MCAMD_ENV_INT("MCAMD_BM192", 1) == 2) t.bm = 192;
     }
     return t;
 }
@@ -431,12 +426,11 @@ static int igemm_mtiles(long long M, int bm) { return (int)((M + bm - 1) / bm); 
 
 // Number of persistent workgroups along M (== rows of the BN-statistics slab).
 int mcamd_igemm_rows(long long M, int n, int cin_tap, int ktot, bool raw_epilogue) {
-    if (raw_epilogue && mcamd_win3x3_fwd_shape(M, n, cin_tap, ktot)) return mcamd_win3x3_fwd_rows();
     TileCfg t = pick_tile(M, n, cin_tap, ktot, raw_epilogue);
     int ntiles = (n + t.bn - 1) / t.bn;
     int mtiles = igemm_mtiles(M, t.bm);
     if (t.kind == 4) return mcamd_small3x3_rows(M);
-    int target = t.kind == 2 ? 256 : env_int("MCAMD_IGEMM_WGS", 2048);   // ping-pong: one workgroup per CU, persistent
+    int target = t.kind == 2 ? 256 : MCAMD_ENV_INT("MCAMD_IGEMM_WGS", 2048);   // ping-pong: one workgroup per CU, persistent
     int p = target / ntiles;
     if (p < 1) p = 1;
     if (p > mtiles) p = mtiles;
@@ -476,9 +470,9 @@ int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st) {
     int rows = mcamd_igemm_rows(a.M, a.N, a.cin_tap, a.ktot, a.mode == MCAMD_EPI_RAW_F16);
     a.num_pslots = rows;
     a.num_ntiles = ntiles;
-    a.xcd_order = env_int("MCAMD_XCD_ORDER", 1);
+    a.xcd_order = MCAMD_ENV_INT("MCAMD_XCD_ORDER", 1);
     if (t.kind == 2) return mcamd_igemm_pp_launch(a, t.bm, t.bn, rows, ntiles, st);
-    const int stages = env_int("MCAMD_STAGES", t.bk == 32 ? 3 : 2);
+    const int stages = MCAMD_ENV_INT("MCAMD_STAGES", t.bk == 32 ? 3 : 2);
 #define I_CASE(BN_, WM_, WN_, BK_, ST_)                              \
     if (!done && t.bm == 128 && t.bn == BN_ && t.bk == BK_ && stages == ST_) { \
         launch_one<128, BN_, WM_, WN_, BK_, ST_>(a, rows, ntiles, st); \

@@ -423,7 +423,7 @@ int mcamd_igemm_pp_launch(const IgemmArgs& a, int bm, int bn, int rows, int ntil
         mcamd_set_error("igemm_pp: K per tap (%d) must be a multiple of %d, tile (%d x %d) 256|192 x 256|128", a.cin_tap, BK, bm, bn);
         return MCAMD_EINVAL;
     }
-    static const int ms = (getenv("MCAMD_PP_MFMA") && atoi(getenv("MCAMD_PP_MFMA")) == 32) ? 32 : 16;
+    const int ms = MCAMD_ENV_INT("MCAMD_PP_MFMA", 16) == 32 ? 32 : 16;
 #define PP_SHAPE(EPI_, BM_, BN_)                                           \
     do {                                                                   \
         if (ms == 32) launch_pp<EPI_, BM_, BN_, 32>(a, rows, ntiles, st);  \

@@ -153,9 +153,7 @@ __global__ __launch_bounds__(256, 1) void small3x3_kernel(IgemmArgs a) {
 }
 
 static int small_groups() {
-    const char* e = getenv("MCAMD_SMALL3X3_U");
-    const int u = e ? atoi(e) : 2;
-    return u == 1 ? 1 : 2;
+    return MCAMD_ENV_INT("MCAMD_SMALL3X3_U", 2) == 1 ? 1 : 2;
 }
 
 // output channel blocks of 16, rounded to a power of two (the store pass needs 64 % (2 blocks) == 0)
@@ -166,8 +164,7 @@ static int small_blocks(int n) { return n <= 16 ? 1 : n <= 32 ? 2 : 4; }
 // than the LDS-staged implicit GEMM: twice the load instructions per pixel, and this kernel's time is
 // proportional to those (the vector memory path delivers ~16 B/clk/CU here).
 bool mcamd_small3x3_ok(long long M, int n, int cin_tap, int ktot) {
-    const char* e = getenv("MCAMD_SMALL3X3");
-    const int lvl = e ? atoi(e) : 1;
+    const int lvl = MCAMD_ENV_INT("MCAMD_SMALL3X3", 1);
     if (lvl == 0) return false;
     if (ktot != 9 * cin_tap || n % 8 != 0 || n > 64 || M < 4096) return false;
     if (cin_tap == 32) return true;

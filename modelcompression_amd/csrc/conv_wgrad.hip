@@ -237,9 +237,6 @@ struct Wgrad9Args {
     int P;               // number of padded pixels B*(H+2)*(W+2)
     int rows_pad, ktot, cin_tap;
     int n_ctiles, n_otiles, nsplit, steps_per_split, nsteps_total;
-    int H, W, M;         // wgrad9i_kernel: image size, number of interior pixels B*H*W
-    int Rw;              // wgrad9i_kernel: rows of its X window
-    int inv_w;           // ceil(65536 / W)
 };
 
 // KP = pixels per step (32 or 64; steps_per_split / nsteps_total are in units of 32 pixels)
@@ -315,142 +312,6 @@ __global__ __launch_bounds__(256, 2) void wgrad9_kernel(Wgrad9Args a) {
             for (int t = 0; t < 9; ++t) {
                 const int shift = (t / 3 - 1) * a.W2 + (t % 3 - 1);
                 bf[t] = tr_frag_rows_builtin<RB>(sx, 16 * s + a.S + shift, wj * 32, lane);
-            }
-#pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[t], acc[t], 0, 0, 0);
-        }
-    }
-
-    float* out = a.slab + (long long)split * a.rows_pad * a.ktot;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int n = ot * 64 + wi * 32 + mfma32_row(r, lane);
-            int k = t * a.cin_tap + ct * 64 + wj * 32 + (lane & 31);
-            out[(long long)n * a.ktot + k] = acc[t][r];
-        }
-}
-
-// ---------------------------------------------------------------------------------------
-// Interior-pixel form of the 9-tap kernel for the SMALL images (13x13: 33 % of the padded pixels are halo).
-//
-// wgrad9_kernel enumerates padded pixels along the reduction dimension, so that a tap is a constant row shift of
-// one X window -- and multiplies the halo pixels (dY = 0 there) too.  ds_read_b64_tr_b16 takes one row address PER
-// LANE, so the rows of a fragment need not be consecutive: here the reduction runs over INTERIOR pixels k only (the
-// dY tile is gathered by the DMA: row r = padded pixel p'(k0 + r)), the X window still holds consecutive PADDED
-// pixels [p'(k0) - S, ...), and the B fragment of tap t reads window row S + (p'(k0 + r) - p'(k0)) + shift_t:
-//     p'(k0 + r) - p'(k0) = r + 2 * floor((w0 + r) / W) + (r >= pixels left in the image ? 2 (W + 2) : 0)
-// (two halo pixels per row wrap, two halo rows at an image boundary; H * W >= KP, so at most one boundary per step).
-// 25 % fewer MFMAs and LDS reads at 13x13 for a window that is 136 instead of 96 rows.
-template <int RB>
-__device__ __forceinline__ h8_t tr_frag_2rows_builtin(const char* tile, int row, int row4, int colbase, int lane) {
-    const int g = lane >> 4, p = lane & 3;
-    const int off = (colbase + 16 * (g & 1) + 4 * p) * 2;
-    const char* p0 = tile + row * RB + ((((off >> 4) ^ tr_swz<RB>(row)) << 4) | (off & 15));
-    const char* p1 = tile + row4 * RB + ((((off >> 4) ^ tr_swz<RB>(row4)) << 4) | (off & 15));
-    union {
-        fp16x4_t h[2];
-        h8_t v;
-    } u;
-    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)p0);
-    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)p1);
-    return u.v;
-}
-
-template <int KP>
-__global__ __launch_bounds__(256, 2) void wgrad9i_kernel(Wgrad9Args a) {
-    constexpr int RB = 128, CH = 8;   // 64 channels = 128 bytes = 8 chunks per row
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wi = wave & 1, wj = wave >> 1;
-    const int R = a.Rw;
-    const int a_bytes = KP * RB, x_bytes = R * RB, stage_bytes = a_bytes + x_bytes;
-    const int HW = a.H * a.W, PW = a.W2, PHW = (a.H + 2) * a.W2;
-
-    const int ntiles = a.n_otiles * a.n_ctiles;
-    const int total_items = ntiles * a.nsplit;
-    const int chunk = (total_items + 7) >> 3;
-    const int item = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= chunk || item >= total_items) return;
-    const int split = item / ntiles;
-    const int tile = item - split * ntiles;
-    const int ot = tile / a.n_ctiles, ct = tile - ot * a.n_ctiles;
-    const int st0 = split * a.steps_per_split;           // steps of KP interior pixels
-    int st1 = st0 + a.steps_per_split;
-    if (st1 > a.nsteps_total) st1 = a.nsteps_total;
-
-    // interior pixel k0 -> (column w0, pixels left in its image, padded index)
-    struct StepPos {
-        int w0, left, pp;
-    };
-    auto pos_of = [&](int st) {
-        const int k0 = st * KP;
-        const int b = k0 / HW, rem = k0 - b * HW;
-        const int h = rem / a.W;
-        StepPos sp;
-        sp.w0 = rem - h * a.W;
-        sp.left = HW - rem;
-        sp.pp = b * PHW + (h + 1) * PW + sp.w0 + 1;
-        return sp;
-    };
-    auto delta = [&](const StepPos& sp, int r) {   // p'(k0 + r) - p'(k0)
-        return r + 2 * (((sp.w0 + r) * a.inv_w) >> 16) + (r >= sp.left ? 2 * PW : 0);
-    };
-
-    const int arow = tid >> 3, achunk = tid & 7;
-    const half_t* dy_col = a.dy + a.dy_off + ot * 64;
-    const half_t* x_base = a.x + a.x_off + ct * 64;
-    const int x_iters = (R * CH + 255) >> 8;
-
-    f32x16_t acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    auto stage = [&](int st, int buf) {
-        const StepPos sp = pos_of(st);
-        char* sa = smem + buf * stage_bytes;
-        char* sx = sa + a_bytes;
-#pragma unroll
-        for (int u = 0; u < KP / 32; ++u) {
-            const int r = 32 * u + arow;
-            const bool live = st * KP + r < a.M;
-            const long long prow = live ? sp.pp + delta(sp, r) : 0;     // padded pixel 0 = halo = 0
-            glds16(dy_col + prow * a.dy_ld + ((achunk ^ tr_swz<RB>(r)) * 8), sa + u * 4096 + wave * 1024);
-        }
-        const long long pb = (long long)sp.pp - a.S;
-        for (int it = 0; it < x_iters; ++it) {
-            const int wslot = it * 256 + wave * 64;
-            if (wslot < R * CH) {
-                const int slot = wslot + lane;
-                const int row = slot >> 3, chunkx = (slot & 7) ^ tr_swz<RB>(row);
-                glds16(x_base + (pb + row) * a.x_ld + chunkx * 8, sx + wslot * 16);
-            }
-        }
-    };
-
-    const int g = lane >> 4, q = (lane & 15) >> 2;
-    if (st1 > st0) stage(st0, 0);
-    for (int st = st0; st < st1; ++st) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (st + 1 < st1) stage(st + 1, (st + 1 - st0) & 1);
-        const StepPos sp = pos_of(st);
-        const char* sa = smem + ((st - st0) & 1) * stage_bytes;
-        const char* sx = sa + a_bytes;
-#pragma unroll
-        for (int s = 0; s < KP / 16; ++s) {
-            const h8_t af = tr_frag_rows_builtin<RB>(sa, 16 * s, wi * 32, lane);
-            const int r0 = 16 * s + 8 * (g >> 1) + q;
-            const int d0 = a.S + delta(sp, r0), d4 = a.S + delta(sp, r0 + 4);
-            h8_t bf[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int shift = (t / 3 - 1) * PW + (t % 3 - 1);
-                bf[t] = tr_frag_2rows_builtin<RB>(sx, d0 + shift, d4 + shift, wj * 32, lane);
             }
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[t], acc[t], 0, 0, 0);
@@ -832,11 +693,6 @@ static int pick_t(int n) {  // largest of 128/64/32 dividing round_up(n, 32)
     return 32;
 }
 
-static int env_int_w(const char* name, int dflt) {
-    const char* s = getenv(name);
-    return s && *s ? atoi(s) : dflt;
-}
-
 // taps per workgroup: as many as keep <= 6 accumulator blocks per wave
 static int pick_taps(int tmo, int tnc, int ntaps) {
     if (ntaps == 1) return 1;
@@ -851,8 +707,8 @@ static int pick_taps(int tmo, int tnc, int ntaps) {
 }
 
 static int pick_kp(int tmo, int tnc, int taps) {
-    if (tmo == 128 && tnc == 128 && taps == 1) return env_int_w("MCAMD_WGRAD_KP_BIG", 32);
-    const int budget = env_int_w("MCAMD_WGRAD_STAGE_KB", 24) * 1024;
+    if (tmo == 128 && tnc == 128 && taps == 1) return MCAMD_ENV_INT("MCAMD_WGRAD_KP_BIG", 32);
+    const int budget = MCAMD_ENV_INT("MCAMD_WGRAD_STAGE_KB", 24) * 1024;
     for (int kp = 128; kp > 32; kp /= 2)
         if (kp * 2 * (tmo + taps * tnc) <= budget) return kp;
     return 32;
@@ -861,11 +717,6 @@ static int pick_kp(int tmo, int tnc, int taps) {
 static int wgrad9_S(int W) { return round_up_int(W + 3, 4); }
 
 // plan of the padded-pixel 9-tap kernel (see wgrad9_kernel); P = padded pixels
-static int wgrad9i_rows(int W, int kp) {   // X window rows of wgrad9i_kernel: the padded span of kp interior pixels + 2 S
-    const int span = kp + 2 * ((W - 1 + kp - 1) / W) + 2 * (W + 2);
-    return round_up_int(span + 2 * wgrad9_S(W), 8);
-}
-
 static WgradPlan wgrad9_plan(long long P, int cout, int cin_tap, int W, int H, int B) {
     WgradPlan p;
     memset(&p, 0, sizeof(p));
@@ -877,7 +728,7 @@ static WgradPlan wgrad9_plan(long long P, int cout, int cin_tap, int W, int H, i
     // workgroups still fit the LDS; the big-image layers (window of 64 + 2(W+3) rows) stay at 32
     p.kp = 32;
     {
-        const int want = env_int_w("MCAMD_WGRAD9_KP", 64);   // 128 (13x13 layers only) measured 1.8x SLOWER
+        const int want = MCAMD_ENV_INT("MCAMD_WGRAD9_KP", 64);   // 128 (13x13 layers only) measured 1.8x SLOWER
         for (int kp = 64; kp <= want && kp <= 128; kp *= 2)
             if (2 * (size_t)(kp + kp + 2 * wgrad9_S(W)) * 128 <= 72 * 1024) p.kp = kp;   // two workgroups per CU: 2 x 72 KB
     }
@@ -890,7 +741,7 @@ static WgradPlan wgrad9_plan(long long P, int cout, int cin_tap, int W, int H, i
     // measured (B = 64): 104x104 layers 0.198 -> 0.149 ms, 52x52 0.144 -> 0.135; 26x26 and 13x13 are within +-4 % (the
     // narrow kernel already executes ~1.1 PFLOP/s of padded-pixel MFMAs there: 33 % of the rows are halo at 13x13)
     // and conv22 (20 channel tiles) is 35 % slower, so the wide form is used from 40 pixels per row up
-    const bool wide = cout % 128 == 0 && env_int_w("MCAMD_WGRAD9W", 1) && W >= env_int_w("MCAMD_WGRAD9W_MINW", 40) &&
+    const bool wide = cout % 128 == 0 && MCAMD_ENV_INT("MCAMD_WGRAD9W", 1) && W >= MCAMD_ENV_INT("MCAMD_WGRAD9W_MINW", 40) &&
                       2 * (size_t)(64 * 256 + (64 + 2 * wgrad9_S(W)) * 128) <= 160 * 1024;
     if (wide) {
         p.nine = 2;
@@ -898,20 +749,10 @@ static WgradPlan wgrad9_plan(long long P, int cout, int cin_tap, int W, int H, i
         p.kp = 64;
         p.n_otiles = p.rows_pad / 128;
     }
-    // interior-pixel form (wgrad9i_kernel) for the small images: no halo pixels in the reduction.  OFF by default:
-    // measured 20 % SLOWER at 13x13 (conv14 0.142 -> 0.169 ms, conv19 0.250 -> 0.305) although it issues 25 % fewer
-    // MFMAs -- with per-lane row addresses every fragment read needs its own row * 128 + swizzle arithmetic (~160 VALU
-    // instructions per 9 MFMAs; the padded form folds them into immediates) and the window grows from 96 to 136 rows.
-    const bool interior = !wide && H > 0 && W <= env_int_w("MCAMD_WGRAD9I_MAXW", 16) && H * W >= 64 && env_int_w("MCAMD_WGRAD9I", 0) &&
-                          2 * (size_t)(64 + wgrad9i_rows(W, 64)) * 128 <= 72 * 1024;
-    if (interior) {
-        p.nine = 3;
-        p.kp = 64;
-    }
     long long tiles = (long long)p.n_otiles * p.n_ctiles;
-    long long nsteps = interior ? ((long long)B * H * W + 63) / 64 * 2 : (P + 31) / 32;   // in 32-pixel units
-    const long long slots = wide ? env_int_w("MCAMD_WGRAD9W_SLOTS", 256) : env_int_w("MCAMD_WGRAD9_SLOTS", 512);
-    long long cap = env_int_w("MCAMD_WGRAD9_WGS", 2048) / tiles;
+    long long nsteps = (P + 31) / 32;   // in 32-pixel units
+    const long long slots = wide ? MCAMD_ENV_INT("MCAMD_WGRAD9W_SLOTS", 256) : MCAMD_ENV_INT("MCAMD_WGRAD9_SLOTS", 512);
+    long long cap = MCAMD_ENV_INT("MCAMD_WGRAD9_WGS", 2048) / tiles;
     if (cap < 1) cap = 1;
     if (cap > nsteps / 8) cap = nsteps / 8 > 0 ? nsteps / 8 : 1;
     long long ns = 1;
@@ -935,7 +776,7 @@ static WgradPlan wgrad9_plan(long long P, int cout, int cin_tap, int W, int H, i
 
 bool mcamd_wgrad_use9(int ksize, int stem, int cout, int cin_tap, int W) {
     return ksize == 3 && !stem && cin_tap % 64 == 0 && cout % 32 == 0 && round_up_int(cout, 64) == round_up_int(cout, 32) &&
-           W <= env_int_w("MCAMD_WGRAD9_MAXW", 208) && env_int_w("MCAMD_WGRAD9", 1);
+           W <= MCAMD_ENV_INT("MCAMD_WGRAD9_MAXW", 208) && MCAMD_ENV_INT("MCAMD_WGRAD9", 1);
 }
 
 WgradPlan mcamd_wgrad_plan9(long long P, int cout, int cin_tap, int W, int H, int B) { return wgrad9_plan(P, cout, cin_tap, W, H, B); }
@@ -963,17 +804,9 @@ int mcamd_wgrad9_launch(const WgradArgs& w, const WgradPlan& p, int W, long long
     a.nsteps_total = (int)((P + 31) / 32);
     const int R = 32 + 2 * a.S;
     const int grid = round_up_int(p.n_otiles * p.n_ctiles * p.nsplit, 8);
-    if (p.nine == 3) {
-        a.H = w.H, a.W = w.W, a.M = w.M;
-        a.Rw = wgrad9i_rows(W, 64);
-        a.inv_w = (65536 + W - 1) / W;
-        a.steps_per_split = p.pix_per_split / 64;
-        a.nsteps_total = (w.M + 63) / 64;
-        const size_t lds = 2 * (size_t)(64 + a.Rw) * 128;
-        hipLaunchKernelGGL(wgrad9i_kernel<64>, dim3(grid), dim3(256), lds, st, a);
-    } else if (p.nine == 2) {
+    if (p.nine == 2) {
         const size_t stage = (size_t)64 * 256 + (size_t)(64 + 2 * a.S) * 128;
-        const int ns = 3 * stage <= 160 * 1024 && env_int_w("MCAMD_WGRAD9W_NS", 3) >= 3 ? 3 : 2;
+        const int ns = 3 * stage <= 160 * 1024 && MCAMD_ENV_INT("MCAMD_WGRAD9W_NS", 3) >= 3 ? 3 : 2;
         MCAMD_LDS_OPT_IN((wgrad9w_kernel<64, 2>), 160 * 1024);
         MCAMD_LDS_OPT_IN((wgrad9w_kernel<64, 3>), 160 * 1024);
         if (ns == 3) hipLaunchKernelGGL((wgrad9w_kernel<64, 3>), dim3(grid), dim3(512), 3 * stage, st, a);
@@ -1008,10 +841,10 @@ WgradPlan mcamd_wgrad_plan(long long M, int cout, int cin_tap, int ntaps) {
     long long tiles = (long long)p.n_otiles * p.n_tapgroups * p.n_ctiles;
     // Pixel splits: fill whole rounds of the machine.  `slots` workgroups run at once (3 per CU at the
     // default 48 KB of LDS); time ~ rounds(ns) / ns, plus the slab traffic that grows with ns.
-    const long long slots = env_int_w("MCAMD_WGRAD_SLOTS", 768);
+    const long long slots = MCAMD_ENV_INT("MCAMD_WGRAD_SLOTS", 768);
     long long max_by_work = (M + 8 * p.kp - 1) / (8 * p.kp);  // at least 8 steps per split
     if (max_by_work < 1) max_by_work = 1;
-    long long cap = env_int_w("MCAMD_WGRAD_WGS", 3072) / tiles;
+    long long cap = MCAMD_ENV_INT("MCAMD_WGRAD_WGS", 3072) / tiles;
     if (cap < 1) cap = 1;
     if (cap > max_by_work) cap = max_by_work;
     long long ns = 1;

@@ -29,12 +29,10 @@ __device__ __forceinline__ void wait_vmc() {
 }
 }  // namespace
 
-// QUAD = false: every wave has its own units and computes all (<= 32) output channels: the input gradient of conv2.
-// QUAD = true: the four waves of a workgroup walk the SAME units and wave w computes output channels [32 w, 32 w + 32)
-// of 128 (forward of conv3/conv5: 64 -> 128 channels at 104x104); each wave still stages its own copy of the window (the
-// four copies are fetched at about the same time and come from L1/L2), BatchNorm partial sums are taken in the store
-// pass and every wave writes its own 32 columns of the workgroup's slab row (no cross-wave reduction).
-template <int NB, bool QUAD>   // 16-channel output blocks per wave (1 | 2); 64 input channels per tap
+// Every wave has its own units and computes all (<= 32) output channels: the input gradient of conv2.  (A four-wave form
+// for the forward of conv3/conv5, 64 -> 128 channels with wave w on channels [32 w, 32 w + 32), measured 0.183 ms against
+// 0.170 ms for the 128x128 implicit GEMM and was removed in round 3: DESIGN.md, negative findings.)
+template <int NB>   // 16-channel output blocks per wave (1 | 2); 64 input channels per tap
 __global__ __launch_bounds__(256, 1) void win3x3_kernel(IgemmArgs a, int seg_rows, int nseg, int nstrips) {
     constexpr int CT = 64, KK = 2, NC = NB * 16, PXB = CT * 2;      // bytes per pixel in the ring
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -43,7 +41,7 @@ __global__ __launch_bounds__(256, 1) void win3x3_kernel(IgemmArgs a, int seg_row
     char* ring = smem + wave * (NR * ROW_BYTES + 1024);
     half_t* tile = (half_t*)(ring + NR * ROW_BYTES);                // [16 pixels][NC channels] of this wave
     const int pl = lane & 15, kg = lane >> 4;
-    const int n0 = QUAD ? wave * NC : 0;                            // first output channel of this wave
+    constexpr int n0 = 0;                                           // first output channel of this wave
 
     // weights: A fragment (row n = n0 + nb*16 + lane & 15, k = t*64 + 32 kk + 8 kg .. +7)
     h8_t wf[9][KK][NB];
@@ -70,13 +68,8 @@ __global__ __launch_bounds__(256, 1) void win3x3_kernel(IgemmArgs a, int seg_row
     };
     const int b_off = pl * PXB + kg * 16;                           // lane's place inside a 16-pixel group of a ring row
 
-    float bs1[8], bs2[8];                                           // BatchNorm partial sums of this lane's 8 channels (QUAD)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bs1[e] = bs2[e] = 0.f;
-    const bool want_stats = QUAD && a.stats != nullptr;
-
     const int nunits = a.M / (a.H * a.W) * nstrips * nseg;
-    const int nwaves = QUAD ? gridDim.x : gridDim.x * 4, gw = QUAD ? blockIdx.x : blockIdx.x * 4 + wave;
+    const int nwaves = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
     for (int unit = gw; unit < nunits; unit += nwaves) {
         const int seg = unit % nseg, rest = unit / nseg;
         const int strip = rest % nstrips, b = rest / nstrips;
@@ -166,14 +159,6 @@ __global__ __launch_bounds__(256, 1) void win3x3_kernel(IgemmArgs a, int seg_row
                             for (int e = 0; e < 8; ++e) s_ |= fabsf((float)v[e]) >= 65504.f;
                             if (s_) atomicOr(a.overflow, 1);
                         }
-                        if (want_stats) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                const float f = (float)v[e];
-                                bs1[e] += f;
-                                bs2[e] += f * f;
-                            }
-                        }
                     }
                 }
             };
@@ -189,46 +174,14 @@ __global__ __launch_bounds__(256, 1) void win3x3_kernel(IgemmArgs a, int seg_row
         }
         wait_vmc<0>();     // the look-ahead rows of this unit must not land in the next unit's ring
     }
-    if (want_stats) {
-        constexpr int RC = NC / 8;                                   // lanes with the same lane % RC hold the same 8 channels
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float v1 = bs1[e], v2 = bs2[e];
-#pragma unroll
-            for (int msk = RC; msk < 64; msk <<= 1) {
-                v1 += __shfl_xor(v1, msk);
-                v2 += __shfl_xor(v2, msk);
-            }
-            if (lane < RC) {
-                a.stats[((long long)blockIdx.x * 2 + 0) * a.stats_ld + n0 + lane * 8 + e] = v1;
-                a.stats[((long long)blockIdx.x * 2 + 1) * a.stats_ld + n0 + lane * 8 + e] = v2;
-            }
-        }
-    }
 }
 
-// dgrad-shaped problems: 3x3, 64 padded input channels, <= 32 outputs, raw fp16 epilogue without statistics;
-// forward-shaped: 64 -> 128 channels, raw fp16 epilogue with or without statistics (one slab row per workgroup)
-static bool win_enabled() {
-    const char* e = getenv("MCAMD_WIN3X3");
-    return !(e && atoi(e) == 0);
-}
-
-// OFF by default: conv3/conv5 forward 0.183 ms against 0.170 ms for the 128x128 implicit GEMM -- the window kernel's
-// per-row sequence (DMA wait, 36 fragment reads, 72 MFMAs, stores; one wave per SIMD) tops out near 700 TFLOP/s,
-// which beats the alternatives on conv2's dgrad (0.25 / 0.35 ms) but not a layer whose GEMM already runs at 600.
-bool mcamd_win3x3_fwd_shape(long long M, int n, int cin_tap, int ktot) {
-    const char* e = getenv("MCAMD_WIN3X3_FWD");
-    if (!win_enabled() || !(e && atoi(e) == 1)) return false;
-    return ktot == 9 * 64 && cin_tap == 64 && n == 128 && M >= 65536;
-}
-
-int mcamd_win3x3_fwd_rows() { return 256; }    // workgroups = rows of the statistics slab
+// dgrad-shaped problems: 3x3, 64 padded input channels, <= 32 outputs, raw fp16 epilogue without statistics
+static bool win_enabled() { return MCAMD_ENV_INT("MCAMD_WIN3X3", 1) != 0; }
 
 bool mcamd_win3x3_ok(const IgemmArgs& a) {
     if (!win_enabled()) return false;
     if (a.mode != MCAMD_EPI_RAW_F16 || a.bias || a.kb != 64 || a.W < 32 || a.H < 8 || a.M % (a.H * a.W) != 0) return false;
-    if (mcamd_win3x3_fwd_shape(a.M, a.N, a.cin_tap, a.ktot)) return true;
     return !a.stats && a.ktot == 9 * 64 && a.cin_tap == 64 && a.N % 8 == 0 && a.N <= 32 && a.W % 16 == 0 && a.M >= 65536;
 }
 
@@ -237,22 +190,21 @@ bool mcamd_win3x3_shape(long long M, int n, int cin_tap, int ktot, int W) {   //
     return ktot == 9 * 64 && cin_tap == 64 && n % 8 == 0 && n <= 32 && W % 16 == 0 && W >= 32 && M >= 65536;
 }
 
-template <int NB, bool QUAD>
+template <int NB>
 static void launch_win3(const IgemmArgs& a, int grid, size_t lds, int seg_rows, int nseg, int nstrips, hipStream_t st) {
-    MCAMD_LDS_OPT_IN((win3x3_kernel<NB, QUAD>), 160 * 1024);   // the window size follows the image width: opt in to the whole LDS
-    hipLaunchKernelGGL((win3x3_kernel<NB, QUAD>), dim3(grid), dim3(256), lds, st, a, seg_rows, nseg, nstrips);
+    MCAMD_LDS_OPT_IN((win3x3_kernel<NB>), 160 * 1024);   // the window size follows the image width: opt in to the whole LDS
+    hipLaunchKernelGGL((win3x3_kernel<NB>), dim3(grid), dim3(256), lds, st, a, seg_rows, nseg, nstrips);
 }
 
 int mcamd_win3x3_launch(const IgemmArgs& a, hipStream_t st) {
-    const bool quad = a.N == 128;
     const int nstrips = (a.W + 31) / 32;
     // Row segments: a wave runs `rounds` units of seg_rows + 4 staged rows (4 = the taps' halo + the look-ahead of the
     // prologue).  Pick the segment length whose units fill whole rounds of the 1024 waves (208 rows, 64 images, 7
-    // strips: 13 rows -> exactly 7 units per wave, 0.150 ms; 16 rows -> 5.7, 0.165 ms).  QUAD: 256 workgroups.
-    const long long runners = quad ? 256 : 1024;
-    const char* es = getenv("MCAMD_WIN3X3_SEG");
-    int want = es && atoi(es) > 0 ? atoi(es) : 0;
-    if (!want) {
+    // strips: 13 rows -> exactly 7 units per wave, 0.150 ms; 16 rows -> 5.7, 0.165 ms).
+    const long long runners = 1024;
+    int want = MCAMD_ENV_INT("MCAMD_WIN3X3_SEG", 0);
+    if (want <= 0) {
+        want = 0;
         const long long per_row_units = (long long)(a.M / (a.H * a.W)) * nstrips;
         double best = 1e30;
         for (int sg = 8; sg <= 32; ++sg) {
@@ -265,14 +217,10 @@ int mcamd_win3x3_launch(const IgemmArgs& a, hipStream_t st) {
     const int nseg = (a.H + want - 1) / want, seg_rows = (a.H + nseg - 1) / nseg;
     const long long units = (long long)(a.M / (a.H * a.W)) * nstrips * nseg;
     const size_t lds = 4 * (size_t)(NR * ROW_BYTES + 1024);
-    if (quad) {
-        launch_win3<2, true>(a, mcamd_win3x3_fwd_rows(), lds, seg_rows, nseg, nstrips, st);
-    } else {
-        long long wgs = (units + 3) / 4;
-        const int grid = (int)(wgs < 256 ? wgs : 256);                         // one workgroup per CU (124 KB of LDS)
-        if ((a.N + 15) / 16 == 1) launch_win3<1, false>(a, grid, lds, seg_rows, nseg, nstrips, st);
-        else launch_win3<2, false>(a, grid, lds, seg_rows, nseg, nstrips, st);
-    }
+    long long wgs = (units + 3) / 4;
+    const int grid = (int)(wgs < 256 ? wgs : 256);                         // one workgroup per CU (124 KB of LDS)
+    if ((a.N + 15) / 16 == 1) launch_win3<1>(a, grid, lds, seg_rows, nseg, nstrips, st);
+    else launch_win3<2>(a, grid, lds, seg_rows, nseg, nstrips, st);
     MCAMD_LAUNCH_CHECK("win3x3");
     return MCAMD_OK;
 }

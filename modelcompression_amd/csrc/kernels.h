@@ -40,23 +40,6 @@ struct StemArgs {        // conv_stem.hip: forward of the 3-channel first layer
     int H, W, HW, M;
 };
 
-struct Igemm9Args {
-    const half_t* x;      // padded pixel (0,0,0), channel 0 of the buffer (x_off added in the kernel)
-    const half_t* w;      // packed weights [Npad][9*cin_tap]
-    void* y;
-    float* stats;
-    const float* scale;
-    const float* shift;
-    int x_ld, x_off;
-    int H, W, W2, HW2;    // real size, W+2, (H+2)*(W+2)
-    int S;                // halo rows of the activation window (multiple of 4, >= W+3)
-    int P;                // padded pixels B*(H+2)*(W+2)
-    int N, ktot, cin_tap;
-    int mode, y_ld, y_choff, stats_ld;
-    float slope;
-    int num_mtiles, num_pslots, num_ntiles;
-};
-
 struct WgradArgs {
     const half_t* x;
     const half_t* dy;
@@ -77,7 +60,7 @@ struct WgradArgs {
 
 struct WgradPlan {
     int tmo, tnc, taps, kp, rows_pad, n_otiles, n_ctiles, n_tapgroups, nsplit, pix_per_split;
-    int nine;   // 1: padded-pixel 9-tap kernel (wgrad9_kernel), 2: its wide form (wgrad9w_kernel), 3: interior-pixel form (wgrad9i_kernel)
+    int nine;   // 1: padded-pixel 9-tap kernel (wgrad9_kernel), 2: its wide form (wgrad9w_kernel)
     int stemw;  // 1: raw-window first-layer kernel (wgrad_stem_kernel), 2: raw-window 32-channel kernel (wgrad_win_kernel)
     size_t bytes;
 };
@@ -106,8 +89,6 @@ int mcamd_colsum_launch(const half_t* dy, long long rows, int ld, int choff, int
 
 bool mcamd_win3x3_ok(const IgemmArgs& a);                             // conv_win.hip
 bool mcamd_win3x3_shape(long long M, int n, int cin_tap, int ktot, int W);
-bool mcamd_win3x3_fwd_shape(long long M, int n, int cin_tap, int ktot);
-int mcamd_win3x3_fwd_rows();
 int mcamd_win3x3_launch(const IgemmArgs& a, hipStream_t st);
 bool mcamd_small3x3_ok(long long M, int n, int cin_tap, int ktot);   // conv_small.hip
 int mcamd_small3x3_rows(long long M);
@@ -116,8 +97,3 @@ int mcamd_small3x3_launch(const IgemmArgs& a, hipStream_t st);
 bool mcamd_stem_direct_ok(int stem, int cout, int mode);
 int mcamd_stem_rows(long long M);
 int mcamd_stem_launch(const StemArgs& a, int cout, hipStream_t st);
-
-bool mcamd_igemm9_ok(int ksize, int stem, int n, int cin_tap, int W, int mode);
-int mcamd_igemm9_S(int W);
-int mcamd_igemm9_rows(long long P, int n);
-int mcamd_igemm9_launch(Igemm9Args& a, hipStream_t st);

@@ -117,6 +117,11 @@ class Engine:
         # tails: +3.5 % images/s at B=64); MCAMD_OVERLAP_WGRAD=0 serialises everything on the launch stream (per-kernel
         # timing passes do that, bench.py)
         self.overlap_wgrad = os.environ.get("MCAMD_OVERLAP_WGRAD", "1") == "1"
+        # every switch is read here, once per engine -- never inside a step
+        self.wgrad_chunk = max(1, int(os.environ.get("MCAMD_WGRAD_CHUNK", "1")))
+        self.overlap_pack = os.environ.get("MCAMD_OVERLAP_PACK", "auto")
+        self.fold_dead = os.environ.get("MCAMD_FOLD_DEAD", "1") == "1"
+        self.bn_narrow_on = os.environ.get("MCAMD_BN_NARROW", "1") == "1"
         self._side_stream = None
         self._side_ws = None
         # set by the backward kernels when a scaled gradient (grad_scale x dY / dX) had to be clamped to +-65504
@@ -499,7 +504,7 @@ class Engine:
         # the launch stream (MCAMD_OVERLAP_PACK=1 forces the overlap, 0 forbids it).
         self._pack_event = None
         side = None
-        want = os.environ.get("MCAMD_OVERLAP_PACK", "auto")
+        want = self.overlap_pack
         if (training and self.overlap_wgrad and self.events is None and self.layers[0].fused_stem
                 and (want == "1" or (want == "auto" and any(lay.fold is not None for lay in self.layers)))):
             main = torch.cuda.current_stream(self.device)
@@ -647,7 +652,7 @@ class Engine:
             self._fold_key = None
             if lay.gin is not None:
                 lay.gin.zero_()       # a folding consumer's dgrad leaves the dead channels of G untouched: they must be finite
-        if not (self.compact and os.environ.get("MCAMD_FOLD_DEAD", "1") == "1"):
+        if not (self.compact and self.fold_dead):
             return 16
         wbytes = 16
         for prod in self.layers:
@@ -668,8 +673,7 @@ class Engine:
             # BatchNorm / activation passes on the kept channels only (their kernels keep one 8-channel group per thread:
             # 8 x a power of two channels); the ones-channel is then written once, here, instead of by every forward pass
             ch = prod.n_act // 8
-            prod.bn_narrow = prod.n_act % 8 == 0 and ch >= 1 and (ch & (ch - 1)) == 0 and ch <= 256 and \
-                os.environ.get("MCAMD_BN_NARROW", "1") == "1"
+            prod.bn_narrow = prod.n_act % 8 == 0 and ch >= 1 and (ch & (ch - 1)) == 0 and ch <= 256 and self.bn_narrow_on
             if prod.bn_narrow:
                 for t in (prod.out_t, prod.out2_t):
                     if t is not None:
@@ -862,7 +866,7 @@ class Engine:
         # blocks per hand-over measured the same (9.63 / 9.64 / 9.64 ms per dense step), 4 and 6 slower (9.71 / 9.75: the
         # late start costs more overlap than the saved events).  dY and the block inputs stay in place until the next
         # forward, so a late start is safe.
-        pending, chunk = [], max(1, int(os.environ.get("MCAMD_WGRAD_CHUNK", "1")))
+        pending, chunk = [], self.wgrad_chunk
 
         def flush():
             if not pending:

@@ -26,3 +26,17 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def setenv(monkeypatch):
+    """setenv(name, value) for the library's MCAMD_* switches: they are cached at first use (never read per launch), so
+    a test that changes one has the library re-read them, and again when the change is undone."""
+    from modelcompression_amd import _lib
+
+    def _set(name, value):
+        monkeypatch.setenv(name, value)
+        _lib.reload_config()
+    yield _set
+    monkeypatch.undo()
+    _lib.reload_config()

@@ -34,18 +34,18 @@ CONV_CASES = [
     (2, 50, 64, 24, 32, 3),       # wgrad_win_kernel<1>, padded input channels
     (4, 128, 144, 32, 64, 3),     # dgrad: win3x3_kernel<2> (rolling LDS window), last strip of a row 16 pixels wide
     (2, 168, 208, 24, 48, 3),     # dgrad: win3x3_kernel<2> with 24 of 32 output channels, 48 of 64 dY channels, ragged row segments
-    (2, 184, 184, 64, 128, 3),    # forward: win3x3_kernel<2, QUAD> (wave = 32 of 128 channels), last group of a row 8 pixels wide
+    (2, 184, 184, 64, 128, 3),    # 64 -> 128 channels on a large image (conv3/conv5-shaped): 128x128 implicit GEMM, ragged last M tile
 ]
 
 
-def test_small3x3_kernel_is_selected(dev, monkeypatch):
-    monkeypatch.setenv("MCAMD_SMALL3X3", "2")                # also the 64-channel-input variants (off by default)
+def test_small3x3_kernel_is_selected(dev, setenv):
+    setenv("MCAMD_SMALL3X3", "2")                # also the 64-channel-input variants (off by default)
     for (B, H, W, cin, cout, k) in CONV_CASES[-8:-5]:
         g = ops.geom(B, H, W, k, cin, cout, ops.round_up(cin, 32))
         assert ops.tile_info(g)[3] == 4 and ops.tile_info(g, dgrad=True)[3] == 4
     g = ops.geom(2, 48, 48, 3, 64, 64, 64)                  # 72 weight fragments: generic kernel
     assert ops.tile_info(g)[3] != 4
-    monkeypatch.setenv("MCAMD_SMALL3X3", "1")
+    setenv("MCAMD_SMALL3X3", "1")
     g = ops.geom(2, 48, 48, 3, 32, 64, 32)
     assert ops.tile_info(g)[3] == 4 and ops.tile_info(g, dgrad=True)[3] != 4
     for (B, H, W, cin, cout, k) in CONV_CASES[-3:-1]:
@@ -74,10 +74,9 @@ def test_layout_nchw_to_padded(dev, C, ld, choff):
 
 @pytest.mark.parametrize("bk", ["32", "64"])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_fwd_raw_and_stats(dev, case, bk, monkeypatch):
-    monkeypatch.setenv("MCAMD_BK", bk)
-    monkeypatch.setenv("MCAMD_SMALL3X3", "2" if bk == "64" else "1")
-    monkeypatch.setenv("MCAMD_WIN3X3_FWD", "1" if bk == "64" else "0")     # rolling-window forward (off by default)
+def test_conv_fwd_raw_and_stats(dev, case, bk, setenv):
+    setenv("MCAMD_BK", bk)
+    setenv("MCAMD_SMALL3X3", "2" if bk == "64" else "1")
     B, H, W, cin, cout, k = case
     x, w = _rand_case(*case)
     xb, ld = to_padded(x.to(dev))
@@ -152,12 +151,11 @@ def test_conv_fwd_padded_epilogue(dev):
     assert halo_is_zero(dst, B, H, W, 128)
 
 
-@pytest.mark.parametrize("minw", ["8", "40"])               # wide 9-tap kernel on the small test images | interior-pixel form
+@pytest.mark.parametrize("minw", ["8", "40"])               # wide 9-tap kernel on the small test images | the narrow form
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_dgrad_wgrad(dev, case, minw, monkeypatch):
-    monkeypatch.setenv("MCAMD_SMALL3X3", "2")
-    monkeypatch.setenv("MCAMD_WGRAD9W_MINW", minw)
-    monkeypatch.setenv("MCAMD_WGRAD9I", "1" if minw == "40" else "0")
+def test_conv_dgrad_wgrad(dev, case, minw, setenv):
+    setenv("MCAMD_SMALL3X3", "2")
+    setenv("MCAMD_WGRAD9W_MINW", minw)
     B, H, W, cin, cout, k = case
     x, w = _rand_case(*case, seed=11)
     gen = torch.Generator().manual_seed(12)
@@ -238,7 +236,7 @@ def test_channel_maps_pack_fwd_dgrad_wgrad(dev, k, cin, cout_full, n_phys):
 
 @pytest.mark.parametrize("B,H,W,cin,cout,k", [(4, 13, 13, 512, 1024, 3), (3, 26, 26, 256, 512, 3), (5, 20, 12, 1024, 256, 1),
                                               (4, 9, 11, 96, 320, 3)])
-def test_pingpong_igemm_vs_igemm(dev, monkeypatch, B, H, W, cin, cout, k):
+def test_pingpong_igemm_vs_igemm(dev, setenv, B, H, W, cin, cout, k):
     """igemm_pp_kernel (ping-pong, conv_igemm_pp.hip; BM 256 / 192, MFMA 32x32x16 / 16x16x32) accumulates over K in
     the same order as igemm_kernel.  With the same MFMA shape its raw fp16 outputs, BN partial sums and fp32 dgrad are
     BIT-identical to igemm_kernel's; with 16x16x32 they are bit-identical between the two tile heights and equal to
@@ -260,14 +258,14 @@ def test_pingpong_igemm_vs_igemm(dev, monkeypatch, B, H, W, cin, cout, k):
         dx = torch.zeros(B, cin, H, W, device=dev)
         ops.conv_dgrad_nchw(g, dyb, dy_ld, 0, wd, dx)
         return y, stats.sum(0), dx, ops.tile_info(g), ops.tile_info(g, dgrad=True)
-    monkeypatch.setenv("MCAMD_PP", "0")
+    setenv("MCAMD_PP", "0")
     y0, s0, dx0, t0, _ = run()
     assert t0[3] == 0
-    monkeypatch.setenv("MCAMD_PP", "2")
+    setenv("MCAMD_PP", "2")
     got = {}
     for bm, bn in ((256, 256), (192, 256), (256, 128), (192, 128)):
-        monkeypatch.setenv("MCAMD_PP_BM", str(bm))
-        monkeypatch.setenv("MCAMD_PP_BN", str(bn))
+        setenv("MCAMD_PP_BM", str(bm))
+        setenv("MCAMD_PP_BN", str(bn))
         for rep in range(4):
             y1, s1, dx1, t1, t1d = run()
             assert t1[3] == 2 and t1[:3] == (bm, bn, 32) and t1d[3] == (2 if cin >= 128 else 0)
@@ -550,7 +548,7 @@ def test_bn_act_fwd_bwd(dev, mode, C):
 
 @pytest.mark.parametrize("mode,dual", [(L.DST_POOL, False), (L.DST_POOL, True), (L.DST_PLAIN, False)])
 @pytest.mark.parametrize("C,y_ld,keep_n", [(64, 128, 40), (16, 64, 16), (256, 256, 200), (1024, 1024, 1024)])
-def test_bn_pool_bwd_fast_equals_generic(dev, monkeypatch, C, y_ld, keep_n, mode, dual):
+def test_bn_pool_bwd_fast_equals_generic(dev, setenv, C, y_ld, keep_n, mode, dual):
     """bn_pool_bwd_kernel (argmax form of the MaxPool BatchNorm backward) and bn_plain_bwd_kernel (hoisted form for PLAIN
     blocks) against the generic kernel on the same inputs: a channel slice of a wider y (filter compaction: BatchNorm on
     the kept channels only), dy_keep zeros, large means, a grid-stride loop of several items per thread."""
@@ -571,8 +569,8 @@ def test_bn_pool_bwd_fast_equals_generic(dev, monkeypatch, C, y_ld, keep_n, mode
     g2 = (torch.randn(M, C, generator=gen)).half().to(dev) if dual else None
     res = []
     for fast in ("0", "1"):
-        monkeypatch.setenv("MCAMD_BN_POOL_FAST", fast)
-        monkeypatch.setenv("MCAMD_BN_PLAIN_FAST", fast)
+        setenv("MCAMD_BN_POOL_FAST", fast)
+        setenv("MCAMD_BN_PLAIN_FAST", fast)
         dy = ops.alloc_padded(B, H, W, C, dev)
         dgm, dbt = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
         ops.bn_act_bwd(B, H, W, C, y, y_ld, 0, scale, shift, mean.contiguous(), invstd.contiguous(), 0.1, mode, g, C, 0,

@@ -1,0 +1,68 @@
+"""Train-mode logits of YOLOv2-VOC against the fp32 oracle, and the step time, per operand precision.
+
+    python tools/train_precision.py [B_parity] [B_time] [steps]
+
+Prints, for precision in fp16 / mixed / fp16x3: rel-L2 of the training-mode logits (batch statistics) against the oracle
+on the same seeded weights and images at B_parity, and ms per fwd+bwd+SGD step at B_time.  north_star's bar for the
+region-layer logits is 1e-3 (reference arithmetic: fp32 F.conv2d, layers.py:59-64)."""
+import os
+import sys
+import time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from modelcompression_amd import nets, YOLOV2_VOC_CFG
+from modelcompression_amd.synthetic import init_synthetic, synthetic_batch
+from oracle import darknet_ref as O
+
+BP = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+BT = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+dev = torch.device("cuda", 0)
+blocks = O.parse_cfg(YOLOV2_VOC_CFG)
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+model = nets.Darknet(YOLOV2_VOC_CFG)
+init_synthetic(model, seed=0)
+state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+x = synthetic_batch(BP, 416, 416, seed=0)
+with torch.no_grad():
+    ref = torch.cat([O.forward(blocks, state, x, training=True)])
+model.to(dev).train()
+for prec in ("fp16", "mixed", "fp16x3"):
+    model.load_state_dict(state)
+    model.precision = prec
+    with torch.no_grad():
+        out = model(x.to(dev))
+    e = rel_l2(out, ref)
+    worst = max(rel_l2(out[i], ref[i]) for i in range(BP))
+    eng = [e_ for e_ in model._engines.values() if e_.precision == prec][0]
+    plain = [l.li + 1 for l in eng.layers if l.level == 1]
+    model._engines = {}
+    # step time at the bench's batch
+    xt = synthetic_batch(BT, 416, 416, seed=1, device=dev)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-5, momentum=0.9, weight_decay=0.0005 * BT, fused=True)
+
+    def step():
+        o = model(xt)
+        loss = o.float().mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / K * 1e3
+    print("%-7s train logits rel-L2 %.2e (worst image %.2e) at B=%d | %.2f ms/step = %.0f img/s at B=%d | plain blocks %s" % (
+        prec, e, worst, BP, ms, BT / ms * 1e3, BT, plain), flush=True)
+    model._engines = {}
+    del opt
