@@ -18,7 +18,10 @@ xGMI link, the same order as the B=32 compute step):
   "fp32"   the flat buffer itself, in place (default; bit-identical ranks);
   "fp16"   each bucket is scaled, rounded to fp16, summed in fp16 and widened again: half the bytes,
            2^-11 relative rounding per element and rank (inside the 1e-3 DP parity bar, outside
-           bit-exactness: opt-in, MCAMD_DP_TRANSPORT=fp16);
+           bit-exactness: opt-in, MCAMD_DP_TRANSPORT=fp16).  A scaled entry beyond 65504 / world (so that the
+           fp16 SUM stays finite) is clamped and raises the reducer's device flag `overflow`: train.py's
+           StepGuard skips that step on every rank and halves `fp16_scale` -- the engine's own policy for its
+           fp16-stored gradients;
   sparse   with STATIC weight masks (`weight_prune`, methods.py:9-26) every masked gradient entry is an
            exact zero on every rank (`grad * mask`, layers.py:59), so only the kept entries travel:
            `set_static_masks` builds the kept-index list once, a bucket is gathered into a packed
@@ -111,6 +114,7 @@ class GradReducer:
         self._kept_pos = None        # {flat offset: number of kept entries below it} at the parameter boundaries
         self._kept_total = 0
         self.prescaled = False       # attach(): the engine already divides every gradient by the world size
+        self.overflow = None         # fp16 transport: device int32[1], set when a scaled entry had to be clamped
 
     # ---- static masks: only the kept entries travel
     def set_static_masks(self, params, masks):
@@ -156,7 +160,16 @@ class GradReducer:
         else:
             idx, src = None, flat[lo:hi]
         if self.transport == "fp16":
-            src = (src * self.fp16_scale).to(torch.float16)
+            # the fp16 SUM over the ranks must stay finite: |entry| <= 65504 / world.  Beyond that the value is clamped
+            # and flagged (no host synchronisation): the step's result is wrong by construction and is skipped by whoever
+            # owns the training loop (train.StepGuard reads `overflow`, all ranks together, and halves fp16_scale)
+            lim = 65504.0 / max(self.world, 1)
+            src = src * self.fp16_scale
+            hit = (src.abs().amax() > lim).to(torch.int32).reshape(1)
+            if self.overflow is None or self.overflow.device != hit.device:
+                self.overflow = torch.zeros(1, dtype=torch.int32, device=hit.device)
+            self.overflow.bitwise_or_(hit)
+            src = src.clamp_(-lim, lim).to(torch.float16)
         elif not sparse:
             src = None                               # fp32 dense: all-reduce the slice in place
         if src is None:
@@ -240,6 +253,16 @@ class GradReducer:
             flat.div_(self.world)
         return flat
 
+    def transport_overflowed(self, reset=True):
+        """True when a bucket of the fp16 transport had to clamp since the last call (one host sync; train.StepGuard
+        reads the device flag without one)."""
+        if self.overflow is None:
+            return False
+        hit = bool(int(self.overflow.item()))
+        if hit and reset:
+            self.overflow.zero_()
+        return hit
+
     def reduce_flat(self, flat):
         if not self.active:
             return flat
@@ -277,6 +300,7 @@ def attach(model, reducer=None, masks=None):
     # averaging rides on the kernels' 1 / grad_scale factor (engine.py backward): no division pass after the all-reduce
     model._grad_div = float(reducer.world) if reducer.active else 1.0
     reducer.prescaled = True
+    model._grad_reducer = reducer               # train.StepGuard folds the transport's overflow flag into its decision
     return reducer
 
 

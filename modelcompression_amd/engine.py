@@ -446,14 +446,20 @@ class Engine:
             w = lay.conv.weight
             m = lay.conv.mask if lay.conv.mask_flag else None
             sig.append((w.data_ptr(), w._version, None if m is None else (m.data_ptr(), m._version)))
+            if lay.fold is not None and not getattr(self, "_training", True):
+                # eval: the folded constants beta - running_mean * gamma / sqrt(running_var + eps) are baked into the
+                # augmented weights -- an in-place change of the producer's BatchNorm tensors (dp.sync_buffers,
+                # running_mean.copy_, load_state_dict) must trigger a re-pack
+                bn = lay.fold.bn
+                sig.append(tuple(t._version for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)))
         return tuple(sig)
 
     def pack(self, force=False, training=True):
         """fp32 master * mask -> fp16 kernel layouts (replaces layers.py:59's per-forward multiply)."""
-        sig = self._signature()
         if any(lay.fold is not None for lay in self.layers) and training != getattr(self, "_training", None):
             force = True          # the folded constants differ between batch and running statistics
         self._training = training
+        sig = self._signature()
         if not force and sig == self._packed_sig and not self.model._weights_dirty:
             return
         mkeys = tuple(None if not lay.conv.mask_flag else (lay.conv.mask.data_ptr(), lay.conv.mask._version)

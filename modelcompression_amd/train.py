@@ -15,16 +15,20 @@ per-epoch prune_rate + are_masks_consistent and a checkpoint every 5th epoch whe
   * MAX_EPOCHS can be given to stop early (the reference hard-codes 135).
 """
 import os
-import time
 
-import torch
-import torch.optim as optim
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL: read when HIP initialises (dp.init_from_env)
 
-from . import dp
-from .data import VOCList, SyntheticDetection
-from .nets import Darknet, parse_cfg
-from .pruning.weightPruning.methods import quick_filter_prune, weight_prune
-from .pruning.weightPruning.utils import prune_rate, are_masks_consistent
+import time  # noqa: E402
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.optim as optim  # noqa: E402
+
+from . import dp  # noqa: E402
+from .data import VOCList, SyntheticDetection  # noqa: E402
+from .nets import Darknet, parse_cfg  # noqa: E402
+from .pruning.weightPruning.methods import quick_filter_prune, weight_prune  # noqa: E402
+from .pruning.weightPruning.utils import prune_rate, are_masks_consistent  # noqa: E402
 
 
 def logging(message):
@@ -34,6 +38,91 @@ def logging(message):
 def file_lines(thefilepath):
     with open(thefilepath, 'rb') as f:
         return sum(buf.count(b'\n') for buf in iter(lambda: f.read(1 << 20), b''))
+
+
+class StepGuard:
+    """The overflow / non-finite policy of a training step WITHOUT a host synchronisation in the step.
+
+    The engine keeps gradients as fp16 x grad_scale and saturates at +-65504 (a device flag per engine records it;
+    RegionLoss's exp terms can push |dL/dlogit| x 256 beyond that), and a non-finite loss must not reach the weights.
+    Round 2 read both on the host every step (`isfinite(loss)`, `grad_overflowed().item()`, an `isfinite` scan of the
+    202 MB gradient buffer and two collectives).  Here:
+      * `decide(loss)` (after backward) folds the engines' flags and `~isfinite(loss)` into ONE device scalar, takes the
+        maximum over the ranks (one 4-byte all-reduce on the stream, so every rank takes the same branch) and hands it
+        to the fused SGD kernel as `found_inf`: a flagged step's update is skipped ON THE DEVICE;
+      * the host reads that scalar one step LATE (pinned copy + event recorded here, consumed by the next call, when
+        the following step is already enqueued): engine overflow -> grad_scale halved for the steps after it, overflow
+        of the fp16 all-reduce transport (dp.GradReducer.overflow) -> its fp16_scale halved, non-finite loss ->
+        FloatingPointError (the reference enters pdb on a NaN loss, train.py:226-231).
+    (The gradient buffer needs no scan of its own: every fp16-writing backward kernel clamps and flags, the fp32
+    finish passes only scale finite values, so a finite loss gives finite gradients.)"""
+
+    def __init__(self, model, optimizer, dev, log=None):
+        self.model, self.opt, self.dev, self.log = model, optimizer, dev, log
+        self.flags = torch.zeros(3, dtype=torch.float32, device=dev)   # [engine overflow, non-finite loss, transport overflow]
+        self.found = torch.zeros(1, dtype=torch.float32, device=dev)
+        optimizer.found_inf = self.found          # torch's fused SGD skips the whole update when this is non-zero
+        # momentum buffers exist (zero) from the start: a skipped FIRST step would otherwise leave them uninitialised
+        # (torch creates them with empty_like on the first call); zero buffers give the same first update, buf = grad
+        for group in optimizer.param_groups:
+            if group.get("momentum", 0):
+                for p in group["params"]:
+                    optimizer.state[p].setdefault("momentum_buffer", torch.zeros_like(p))
+        self._host = torch.zeros(3, dtype=torch.float32)
+        if dev.type == "cuda":
+            self._host = self._host.pin_memory()
+        self._event, self._pending = None, False
+        self.skipped = 0
+        self._collective = dist.is_initialized() and (dist.get_world_size() > 1 or dp.rehearsal())
+
+    def consume(self):
+        """Act on the flag of the step BEFORE the one just enqueued (no-op when there is none)."""
+        if not self._pending:
+            return 0
+        if self._event is not None:
+            self._event.synchronize()             # that step is long done unless the host runs a whole step ahead
+        over, bad, tover = (bool(v) for v in self._host.tolist())
+        self._pending = False
+        if bad:
+            raise FloatingPointError("non-finite training loss")
+        if over or tover:
+            self.skipped += 1
+        if over:
+            self.model.grad_scale = max(1.0, self.model.grad_scale / 2.0)
+            if self.log:
+                self.log('gradient overflow in fp16 storage: step skipped, grad_scale -> %g' % self.model.grad_scale)
+        if tover:
+            red = self.model._grad_reducer
+            red.fp16_scale = max(1.0 / 65536.0, red.fp16_scale / 2.0)
+            if self.log:
+                self.log('gradient overflow in the fp16 all-reduce transport: step skipped, fp16_scale -> %g' % red.fp16_scale)
+        return int(over) + 2 * int(bad) + 4 * int(tover)
+
+    def decide(self, loss):
+        """Call between backward() and optimizer.step()."""
+        self.consume()
+        flags = [eng.overflow for eng in getattr(self.model, "_engines", {}).values()]
+        zero = torch.zeros((), dtype=torch.float32, device=self.dev)
+        over = torch.stack([f.reshape(()) for f in flags]).sum().clamp(max=1).to(torch.float32) if flags else zero
+        bad = (~torch.isfinite(loss.detach())).to(torch.float32).reshape(())
+        red = getattr(self.model, "_grad_reducer", None)
+        tflag = red.overflow if red is not None else None
+        tover = tflag.reshape(()).clamp(max=1).to(torch.float32) if tflag is not None else zero
+        self.flags.copy_(torch.stack((over, bad, tover)))
+        for f in flags + ([tflag] if tflag is not None else []):
+            f.zero_()
+        if self._collective:
+            dist.all_reduce(self.flags, op=dist.ReduceOp.MAX)
+        self.found.copy_(self.flags.sum().reshape(1))
+        self._host.copy_(self.flags, non_blocking=True)
+        if self.dev.type == "cuda":
+            self._event = torch.cuda.Event()
+            self._event.record()
+        self._pending = True
+
+    def finish(self):
+        """End of an epoch / run: the last step's flag."""
+        return self.consume()
 
 
 class YOLOv2Train():
@@ -116,6 +205,7 @@ class YOLOv2Train():
         loader = torch.utils.data.DataLoader(dataset, batch_size=per_rank, shuffle=(sampler is None), sampler=sampler,
                                              num_workers=4 if isinstance(dataset, VOCList) else 0, pin_memory=True,
                                              drop_last=True)
+        guard = StepGuard(self.model, optimizer, dev, log=logging if rank == 0 else None)
         epoch = init_epoch
         for epoch in range(init_epoch, min(MAX_EPOCHS, 135)):
             if sampler is not None:
@@ -123,7 +213,9 @@ class YOLOv2Train():
             if rank == 0:
                 print(' ---------------------------- EPOCH : ', epoch, ' (LR : ', LR, ') ---------------------------------- ')
             self.model.train()
-            train_loss_total, t0, seen_here, skipped_steps = 0.0, time.time(), 0, 0
+            # the loss is accumulated on the device and read once per epoch; the skip policy lives in StepGuard
+            train_loss_total, t0, steps_here = torch.zeros((), dtype=torch.float32, device=dev), time.time(), 0
+            skipped_before = guard.skipped
             for batch_idx, (data, target) in enumerate(loader):
                 if DEBUG_EPOCHS > -1 and batch_idx > DEBUG_EPOCHS:
                     break
@@ -132,28 +224,20 @@ class YOLOv2Train():
                 output = self.model(data)
                 region_loss.seen = region_loss.seen + data.size(0) * world
                 train_loss = region_loss(output, target)
-                # every decision below is taken by all ranks together: a rank that raised or skipped alone would
-                # leave its peers blocked in the next gradient all-reduce
-                if not dp.all_ranks_ok(bool(torch.isfinite(train_loss)), dev):
-                    raise FloatingPointError("non-finite training loss at epoch %d batch %d" % (epoch, batch_idx))
-                train_loss_total += float(train_loss.detach())
+                train_loss_total += train_loss.detach()
                 optimizer.zero_grad()
                 train_loss.backward()
-                # the engine keeps gradients as fp16 x grad_scale and saturates at +-65504 (RegionLoss's exp terms can
-                # produce |dL/dlogit| x 256 beyond that): such a step is skipped and the scale halved
-                flat = self.model._last_flat_grad
-                good = not self.model.grad_overflowed() and (flat is None or bool(torch.isfinite(flat).all()))
-                if not dp.all_ranks_ok(good, dev):
-                    self.model.grad_scale = max(1.0, self.model.grad_scale / 2.0)
-                    skipped_steps += 1
-                    if rank == 0:
-                        logging('gradient overflow in fp16 storage: step skipped, grad_scale -> %g' % self.model.grad_scale)
-                    continue
+                # no host synchronisation here: a saturated / non-finite step is skipped on the device, by all ranks
+                # together, and the host learns of it one step late (StepGuard)
+                guard.decide(train_loss)
                 optimizer.step()
-                seen_here += data.size(0) * world
+                steps_here += 1
                 if verbose and rank == 0:
                     print(' - loss : ', float(train_loss.detach()))
+            guard.finish()
             torch.cuda.synchronize()
+            seen_here = (steps_here - (guard.skipped - skipped_before)) * per_rank * world
+            train_loss_total = float(train_loss_total)
             if rank == 0:
                 logging('training with %f samples/s, mean loss %.4f' % (seen_here / max(time.time() - t0, 1e-9),
                                                                          train_loss_total / max(len(loader), 1)))

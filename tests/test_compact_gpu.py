@@ -201,9 +201,10 @@ def test_compaction_yolov2_40pct(dev):
 
 @pytest.mark.parametrize("cfg,shape", [(MINI, (4, 3, 64, 96)), (YOLOV2_VOC_CFG, (4, 3, 416, 416))], ids=["mini", "yolov2"])
 def test_overlapped_wgrad_with_compaction_is_bit_identical(dev, cfg, shape):
-    """MCAMD_OVERLAP_WGRAD=1 runs the weight gradients of the non-gather layers on a second stream while the gather
-    layers (filter compaction) keep theirs on the main stream: the two must not share a split-K workspace
-    (ADVICE r01).  Every kernel is deterministic, so the gradients have to be bit-identical to the serial run."""
+    """MCAMD_OVERLAP_WGRAD=1 runs EVERY weight gradient -- gather layers (filter compaction, folded inputs) included,
+    with their unfold / scatter passes -- on the second stream with its own split-K workspace, while the dgrad /
+    BatchNorm-backward chain stays on the launch stream.  Every kernel is deterministic, so the gradients have to be
+    bit-identical to the serial run."""
     blocks, m, masks = _model(cfg, dev, 7, 40.0)
     g = torch.Generator().manual_seed(21)
     x = torch.rand(*shape, generator=g).to(dev)

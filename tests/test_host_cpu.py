@@ -253,6 +253,57 @@ def _dp_worker(rank, world, port, tmp):
         assert float((flat - dense).abs().max()) <= 2.0 ** -10 * float(dense.abs().max()) + 1e-6
         assert h.bytes_reduced == 2 * (int(full.sum()) if sparse else total)
         assert bool((flat[full == 0] == 0).all())
+    # ---- fp16 transport overflow: an entry whose scaled value exceeds 65504 / world is clamped and FLAGGED,
+    # never inf; train.StepGuard turns the flag into "skip on every rank, halve fp16_scale" without a host sync in the step
+    h = dp.GradReducer(transport="fp16")
+    flat = torch.tensor([300.0, 1.0, -2.0]) if rank == 0 else torch.tensor([1.0, 1.0, 1.0])
+    h.reduce_flat(flat)
+    assert bool(torch.isfinite(flat).all()) and h.transport_overflowed() == (rank == 0) and not h.transport_overflowed()
+    flat = torch.tensor([3.0, 1.0, -2.0])
+    h.reduce_flat(flat)
+    assert not h.transport_overflowed() and torch.allclose(flat, torch.tensor([3.0, 1.0, -2.0]))
+
+    from modelcompression_amd.train import StepGuard
+
+    class Eng:
+        def __init__(self):
+            self.overflow = torch.zeros(1, dtype=torch.int32)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(4))
+            self._engines, self.grad_scale = {"e": Eng()}, 256.0
+    net = Net()
+    net._grad_reducer = h
+    opt = torch.optim.SGD(net.parameters(), lr=0.5, momentum=0.9, fused=True)
+    guard = StepGuard(net, opt, torch.device("cpu"))
+
+    def one_step(engine_over=False, transport_grad=1.0, loss=1.0):
+        net.w.grad = torch.full((4,), transport_grad if rank == 0 else 1.0)
+        h.reduce_flat(net.w.grad)                           # averaged over the two ranks
+        if engine_over:
+            net._engines["e"].overflow.fill_(1)
+        guard.decide(torch.tensor(loss))
+        opt.step()
+    one_step()                                              # clean: w = 1 - 0.5 * 1
+    assert torch.allclose(net.w.detach(), torch.full((4,), 0.5)) and guard.skipped == 0
+    one_step(engine_over=(rank == 1))                       # rank 1 alone saturated: BOTH ranks skip
+    assert torch.allclose(net.w.detach(), torch.full((4,), 0.5))
+    one_step(transport_grad=300.0)                          # (the late read of the step before: grad_scale halved)
+    assert guard.skipped == 1 and net.grad_scale == 128.0 and int(net._engines["e"].overflow) == 0
+    assert torch.allclose(net.w.detach(), torch.full((4,), 0.5))       # rank 0's 300 x 256 overflowed the transport: skipped
+    one_step()
+    assert guard.skipped == 2 and h.fp16_scale == 128.0
+    mom = 0.9 * 1.0 + 1.0                                   # momentum buffer after the two real updates
+    assert torch.allclose(net.w.detach(), torch.full((4,), 0.5 - 0.5 * mom))
+    assert guard.finish() == 0
+    try:
+        one_step(loss=float("nan") if rank == 0 else 1.0)   # a non-finite loss on ONE rank raises on both, one step late
+        guard.finish()
+        raise AssertionError("non-finite loss accepted")
+    except FloatingPointError:
+        pass
     # ---- collective decisions and buffer averaging
     assert dp.all_ranks_ok(True) is True
     assert dp.all_ranks_ok(rank != 1) is False
