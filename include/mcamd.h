@@ -357,6 +357,11 @@ int mcamd_stem_block_bwd(const mcamd_stem_block_desc* d, void* workspace, size_t
 int mcamd_nchw_f32_to_padded_nhwc_f16(const float* src, int32_t B, int32_t C, int32_t H, int32_t W,
                                       float mul, void* dst, int32_t dst_ld, int32_t dst_choff, int32_t* overflow,
                                       void* stream);
+/* The same into split storage (mcamd_act_desc.planes == 3): channel c of the image is written as hi = fp16(v) at
+ * dst_choff + c, lo = fp16(v - hi) at dst_choff + plane + c and hi again at dst_choff + 2 * plane + c -- the network
+ * input of the "fp16x3" / "mixed" precision modes (nets.py:720 takes the image as fp32 NCHW). */
+int mcamd_nchw_f32_to_padded_nhwc_f16_split(const float* src, int32_t B, int32_t C, int32_t H, int32_t W,
+                                            void* dst, int32_t dst_ld, int32_t dst_choff, int32_t plane, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Pruning (reference src/pruning/weightPruning/methods.py).

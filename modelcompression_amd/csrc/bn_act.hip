@@ -680,7 +680,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* slab
 // NCHW fp32 -> padded NHWC fp16 (model boundary)
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, int B, int C, int H, int W, float mul,
-                                                           half_t* dst, int ld, int choff, int cgroups, int* overflow) {
+                                                           half_t* dst, int ld, int choff, int cgroups, int* overflow,
+                                                           int plane) {
     bool sat = false;
     // item = (pixel, channel group of up to 8); consecutive threads -> consecutive pixels (coalesced NCHW reads)
     const long long HW = (long long)H * W;
@@ -697,7 +698,15 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, int
         int nc = C - c0 < 8 ? C - c0 : 8;
         if (overflow)
             for (int i = 0; i < nc; ++i) sat |= fabsf(s[i * HW] * mul) > 65504.f;
-        if (ld == 4) {  // stem image: 3 channels + one zero, one 8-byte store per pixel
+        if (plane > 0) {  // split storage: hi | lo | hi planes, `plane` channels apart (mcamd_act_desc.planes)
+            for (int i = 0; i < nc; ++i) {
+                const float v = s[i * HW] * mul;
+                const half_t hi = sat_half(v);
+                d[i] = hi;
+                d[plane + i] = (half_t)(v - (float)hi);
+                d[2 * plane + i] = hi;
+            }
+        } else if (ld == 4) {  // stem image: 3 channels + one zero, one 8-byte store per pixel
             h4_t q;
 #pragma unroll
             for (int i = 0; i < 4; ++i) q[i] = (i < nc) ? sat_half(s[i * HW] * mul) : (half_t)0.f;
@@ -929,7 +938,21 @@ extern "C" int mcamd_nchw_f32_to_padded_nhwc_f16(const float* src, int32_t B, in
     int cgroups = (C + 7) / 8;
     long long items = (long long)B * H * W * cgroups;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(stream_grid(items)), dim3(256), 0, (hipStream_t)stream, src, B, C, H, W,
-                       mul, (half_t*)dst, dst_ld, dst_choff, cgroups, (int*)overflow);
+                       mul, (half_t*)dst, dst_ld, dst_choff, cgroups, (int*)overflow, 0);
     MCAMD_LAUNCH_CHECK("nchw_to_nhwc");
+    return MCAMD_OK;
+}
+
+extern "C" int mcamd_nchw_f32_to_padded_nhwc_f16_split(const float* src, int32_t B, int32_t C, int32_t H, int32_t W,
+                                                       void* dst, int32_t dst_ld, int32_t dst_choff, int32_t plane,
+                                                       void* stream) {
+    MCAMD_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc_split: bad argument");
+    MCAMD_REQUIRE(plane >= C && dst_choff + 2 * plane + C <= dst_ld, "nchw_to_nhwc_split: three planes of %d channels, %d apart, exceed ld %d",
+                  C, plane, dst_ld);
+    int cgroups = (C + 7) / 8;
+    long long items = (long long)B * H * W * cgroups;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(stream_grid(items)), dim3(256), 0, (hipStream_t)stream, src, B, C, H, W,
+                       1.0f, (half_t*)dst, dst_ld, dst_choff, cgroups, (int*)nullptr, plane);
+    MCAMD_LAUNCH_CHECK("nchw_to_nhwc_split");
     return MCAMD_OK;
 }

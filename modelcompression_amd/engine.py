@@ -727,9 +727,11 @@ class Engine:
         tin = self.layers[0].tin
         xs = x.detach().contiguous().float()
         if self.precise and not self.stem:        # the image too is an MFMA operand: hi | lo | hi planes
-            hi = xs.half().float()
-            xs = torch.cat((hi, xs - hi, hi), 1).contiguous()
-        ops.nchw_to_padded(xs, self.bufs[tin.buf], tin.ld, tin.choff)
+            # (written by the layout kernel itself: round 2 built the planes with torch.cat, three 3 x B x H x W fp32
+            # temporaries per forward -- 0.8 GB at B=128 through the caching allocator)
+            ops.nchw_to_padded_split(xs, self.bufs[tin.buf], tin.ld, tin.choff, tin.ps)
+        else:
+            ops.nchw_to_padded(xs, self.bufs[tin.buf], tin.ld, tin.choff)
         out = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
         for lay in self.layers:
             xin = self.bufs[lay.tin.buf]

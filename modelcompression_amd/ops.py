@@ -366,6 +366,15 @@ def nchw_to_padded(src, dst, dst_ld, dst_choff=0, mul=1.0, overflow=None):
                                                     ptr(overflow), stream_ptr()), "mcamd_nchw_f32_to_padded_nhwc_f16")
 
 
+def nchw_to_padded_split(src, dst, dst_ld, dst_choff, plane):
+    """fp32 NCHW image -> hi | lo | hi planes (`plane` channels apart) of a padded NHWC fp16 buffer."""
+    _need_cuda(src, dst)
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    B, C_, H, W = src.shape
+    check(L.lib().mcamd_nchw_f32_to_padded_nhwc_f16_split(ptr(src), B, C_, H, W, ptr(dst), dst_ld, dst_choff, plane,
+                                                          stream_ptr()), "mcamd_nchw_f32_to_padded_nhwc_f16_split")
+
+
 # ------------------------------------------------------------------ pruning
 def kth_magnitude(tensors, k):
     """-> device fp32[2] = (s[k], s[min(k+1, n-1)]) of the ascending |w| over all tensors."""

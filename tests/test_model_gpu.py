@@ -72,6 +72,29 @@ def test_mini_train_fp16x3_vs_golden(dev):
     assert e2 < 1e-4
 
 
+def test_mini_train_mixed_vs_golden(dev):
+    """The "mixed" training precision (the 1e-3-compliant mode bench.py times next to plain fp16): train logits within
+    1e-3 of the reference's golden run, running statistics as the reference updates them."""
+    gold = np.load(os.path.join(HERE, "golden", "mini_fwd_bwd.npz"))
+    m, blocks, state = _mini_model(dev)
+    m.precision = "mixed"
+    m.train()
+    x, gout = torch.from_numpy(gold["x"]), torch.from_numpy(gold["gout"])
+    out = m(x.to(dev))
+    out.backward(gout.to(dev))
+    e = rel_l2(out.detach().cpu(), torch.from_numpy(gold["train_logits"]))
+    print("mini train logits, mixed precision, rel-L2 vs reference: %.2e" % e)
+    assert e < 1e-3
+    _, fl_grads = _oracle_run(blocks, state, x, gout, "fp16")
+    for name, p in m.named_parameters():
+        ref = torch.from_numpy(gold["grad/" + name])
+        assert rel_l2(p.grad.cpu(), ref) < 1.5 * rel_l2(fl_grads[name], ref) + 2e-3, name
+    sd = m.state_dict()
+    for k in sd:
+        if "running_" in k:
+            assert torch.allclose(sd[k].cpu(), torch.from_numpy(gold["after/" + k]), rtol=2e-3, atol=2e-4), k
+
+
 def _oracle_run(blocks, state, x, gout, storage, masks=None):
     st = {k: v.clone() for k, v in state.items()}
     for k in O.param_keys(blocks):
@@ -277,10 +300,36 @@ def _teacher_forced(dev, cfg, B, seed, masked, hw=None, only=None, grad_scale=No
             rec("stem_block_wgrad", rel_l2(dw2.cpu(), gw), 1e-3, lay)
             rec("stem_block_dgamma", rel_l2(dg2.cpu(), gam.grad), 2e-3, lay)
             rec("stem_block_dbeta", rel_l2(db2.cpu(), bet.grad), 2e-3, lay)
-            # what the training step itself produced (all of G): the same up to those pixels
-            # (sanity only: a sum of N random-sign terms moves by ~sqrt(f) when a fraction f of them is dropped)
-            rec("stem_block_wgrad_all", rel_l2(lay.conv.weight.grad.cpu(), dw2.cpu()), 0.3, lay)
-            rec("stem_block_dbeta_all", rel_l2(lay.bn.bias.grad.cpu(), db2.cpu()), 0.3, lay)
+            # What the training step ITSELF produced (all of G, nothing excluded) against the float64 reference on all of G.
+            # The bar is measured, not chosen: (1) `env`, a rigorous envelope of what the one-sided-derivative choice can
+            # do to dbeta -- at a pooled pixel whose winning pre-activation is within 1e-5 of 0 the LeakyReLU derivative
+            # is 1 or `slope`, so dbeta_c can move by at most (1 - slope) * sum |G| over those pixels of channel c;
+            # (2) `spread`, what torch's OWN float32 arithmetic does on this seed: the same block in fp32 F.conv2d /
+            # batch_norm against the float64 run (the claim "the reference's float32 arithmetic does the same", now
+            # tested: it must sit inside the same envelope).  The engine gets 3 x max(env, spread) + the kernel bar.
+            del o, z
+            def block_grads(dt):
+                w_ = wq.detach().to(dt).requires_grad_(True)
+                g_ = lay.bn.weight.detach().cpu().to(dt).requires_grad_(True)
+                b_ = lay.bn.bias.detach().cpu().to(dt).requires_grad_(True)
+                z_ = F.batch_norm(F.conv2d(X.to(dt), w_, None, 1, 1), None, None, g_, b_, True, 0.1, 1e-5)
+                (F.max_pool2d(F.leaky_relu(z_, lay.slope), 2, 2) * G.to(dt)).sum().backward()
+                return (w_.grad * mask.to(dt) if mask is not None else w_.grad), b_.grad, z_.detach()
+            w64, b64, z64 = block_grads(torch.float64)
+            w32, b32, _ = block_grads(torch.float32)
+            amb = torch.zeros(lay.cout, dtype=torch.float64)
+            for b0 in range(0, B, 4):
+                zmax = F.max_pool2d(z64[b0:b0 + 4], 2, 2)
+                amb += ((zmax.abs() < 1e-5) * G[b0:b0 + 4].abs().double()).sum((0, 2, 3))
+            del z64
+            env = float(((1.0 - lay.slope) * amb * alive_f).norm() / b64.norm())
+            sp_w, sp_b = rel_l2(w32, w64), rel_l2(b32, b64)
+            e_w, e_b = rel_l2(lay.conv.weight.grad.cpu(), w64), rel_l2(lay.bn.bias.grad.cpu(), b64)
+            print("    stem block, all of G vs float64: engine dW %.2e dbeta %.2e | torch float32 dW %.2e dbeta %.2e | "
+                  "one-sided-derivative envelope of dbeta %.2e" % (e_w, e_b, sp_w, sp_b, env))
+            assert sp_b <= env + 1e-5, "torch's float32 run left the envelope: the envelope is wrong"
+            rec("stem_block_wgrad_all", e_w, 3.0 * max(env, sp_w) + 1e-3, lay)
+            rec("stem_block_dbeta_all", e_b, 3.0 * max(env, sp_b) + 2e-3, lay)
             if mask is not None:
                 assert bool((lay.conv.weight.grad.cpu()[mask == 0] == 0).all()) and bool((dw2.cpu()[mask == 0] == 0).all())
             continue
@@ -586,6 +635,18 @@ def test_yolov2_train_step_vs_oracle(dev):
     e, floor = rel_l2(out.detach().cpu(), ref_out), rel_l2(fl_out, ref_out)
     print("yolov2-voc train logits rel-L2 vs fp32 oracle: %.2e (fp16-storage floor %.2e)" % (e, floor))
     assert e < 1.5 * floor + 1e-3
+    for name, p in m.named_parameters():
+        ge, gf = rel_l2(p.grad.cpu(), ref_g[name]), rel_l2(fl_g[name], ref_g[name])
+        assert ge < 1.5 * gf + 5e-3, (name, ge, gf)
+    # the training precision that MEETS north_star's 1e-3 on the region-layer logits: "mixed" (split hi/lo operands on all
+    # but the costliest blocks; bench.py reports its throughput as config.tolerance_mode)
+    m.precision = "mixed"
+    m.zero_grad()
+    out_m = m(x.to(dev))
+    out_m.backward(gout.to(dev))
+    e_m = rel_l2(out_m.detach().cpu(), ref_out)
+    print("yolov2-voc train logits, mixed precision, rel-L2 vs fp32 oracle: %.2e" % e_m)
+    assert e_m < 1e-3
     for name, p in m.named_parameters():
         ge, gf = rel_l2(p.grad.cpu(), ref_g[name]), rel_l2(fl_g[name], ref_g[name])
         assert ge < 1.5 * gf + 5e-3, (name, ge, gf)

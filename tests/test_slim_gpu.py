@@ -3,8 +3,9 @@ slim conv shapes, inference, B=128, fp16 MFMA path).
 
 Parity target = the reference's masked-dense network (the reference has no slim implementation):
 the fp32 oracle at small batch, and the product's own masked-dense engine at B=128.
-Tolerance: logits within a small multiple of 1e-3 relative L2 (23 layers of fp16 storage, same
-bounds as test_model_gpu.py's eval tests)."""
+Tolerance: north_star's 1e-3 relative L2 on the logits in the default eval precision ("mixed"); the plain-fp16
+MFMA mode the config names for throughput is held to the masked-dense engine's own distance from the oracle in
+that mode (its floor: 2.9e-4 per block in quadrature, tools/error_budget.py)."""
 import os
 import time
 
@@ -49,7 +50,7 @@ def test_slim_mini_vs_oracle_and_dense_engine(dev, tmp_path, perc):
     e_ref, e_dense, d_ref = rel_l2(thin, ref), rel_l2(thin, dense), rel_l2(dense, ref)
     print("mini %g%%: slim vs fp32 oracle %.2e, slim vs dense engine %.2e (dense engine vs oracle %.2e)"
           % (perc, e_ref, e_dense, d_ref))
-    assert e_ref < 2e-3 and e_dense < 2e-3
+    assert e_ref < 1e-3 and e_dense < 1e-3
 
 
 def test_slim_is_inference_only(dev, tmp_path):
@@ -77,7 +78,14 @@ def test_slim_yolov2_60pct_b128(dev, tmp_path):
                          masks=[k.cpu() for k in masks])
     e1 = rel_l2(thin1, ref1)
     print("slim B=1 logits vs fp32 masked-dense oracle: rel-L2 %.2e" % e1)
-    assert thin1.shape == (1, 125, 13, 13) and e1 < 5e-3
+    assert thin1.shape == (1, 125, 13, 13) and e1 < 1e-3
+    # the plain-fp16 mode (the one bench.py --workload slim60 quotes): against the floor the masked-dense engine shows
+    with torch.no_grad():
+        s.precision = m.precision = "fp16"
+        e1h, d1h = rel_l2(s(x1.to(dev)).cpu(), ref1), rel_l2(m(x1.to(dev)).cpu(), ref1)
+        s.precision = m.precision = "auto"
+    print("plain fp16 operands: slim vs oracle %.2e, masked-dense engine vs oracle %.2e" % (e1h, d1h))
+    assert e1h < 1.5 * d1h + 5e-4 and e1h < 2.5e-3
     # B = 128 against the masked-dense engine, and how much faster the slim shapes run
     x = torch.rand(128, 3, 416, 416, generator=torch.Generator().manual_seed(5)).to(dev)
     with torch.no_grad():
@@ -85,21 +93,26 @@ def test_slim_yolov2_60pct_b128(dev, tmp_path):
         dense = m(x)
         e = rel_l2(thin.cpu(), dense.cpu())
         print("slim B=128 logits vs masked-dense engine: rel-L2 %.2e" % e)
-        assert e < 5e-3
+        assert e < 1e-3
         times = {}
         for name, net in (("dense", m), ("slim", s)):
-            # best of five single forwards, not a mean: behind the 4-minute test_model_gpu.py in one process the mean of
-            # three slim forwards came out at 20 ms once (12 ms for the masked-dense net, logits correct, 6 ms when the
-            # file runs alone) -- a one-off stall (most likely the caching allocator going back to hipMalloc for the
-            # 265 MB input conversion), not the kernels' time, which is what this assertion is about
-            best = float("inf")
+            # MEAN of five forwards.  Round 2 saw 20 ms once where 6 ms is normal (behind test_model_gpu.py in one process)
+            # and took the best of five instead.  The cause was in the engine: the split-operand ("mixed") forward of a
+            # slim model built its hi | lo | hi image planes with torch.cat -- 0.8 GB of fp32 temporaries per forward at
+            # B=128, served by hipMalloc (and hipFree of cached blocks) whenever the caching allocator's pool had been
+            # carved up by the tests before.  The layout kernel writes the planes itself now
+            # (mcamd_nchw_f32_to_padded_nhwc_f16_split) and a warm forward allocates nothing from the device: asserted.
+            net(x)
+            torch.cuda.synchronize()
+            before = torch.cuda.memory_stats(dev)
+            t0 = time.perf_counter()
             for _ in range(5):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
                 net(x)
-                torch.cuda.synchronize()
-                best = min(best, time.perf_counter() - t0)
-            times[name] = best
+            torch.cuda.synchronize()
+            times[name] = (time.perf_counter() - t0) / 5
+            after = torch.cuda.memory_stats(dev)
+            assert after["num_device_alloc"] == before["num_device_alloc"] and after["num_alloc_retries"] == before["num_alloc_retries"], \
+                "a warm eval forward went to hipMalloc (%s)" % name
     print("B=128 eval forward: masked dense %.1f ms (%.0f img/s), slim %.1f ms (%.0f img/s)"
           % (times["dense"] * 1e3, 128 / times["dense"], times["slim"] * 1e3, 128 / times["slim"]))
     assert times["slim"] < times["dense"]
