@@ -254,8 +254,11 @@ class Darknet(nn.Module):
         self.grad_scale = 256.0         # fp16 gradient scaling inside the engine, undone in fp32
         # Operand precision of the forward convolutions (engine.py): "fp16" (throughput), "fp16x3" (split hi/lo
         # operands, three fp16 MFMA products per multiply), "mixed" (split except on the costliest blocks the 1e-3
-        # logit budget leaves plain), or "auto" = "fp16" while training, "mixed" in eval mode -- so that inference
-        # reproduces the reference's fp32 region-layer logits within 1e-3 (north_star) by default.
+        # logit budget leaves plain -- in eval AND in training, where the budget is tighter: engine.MIXED_BUDGET_TRAIN),
+        # or "auto" = "fp16" while training, "mixed" in eval mode -- so that inference reproduces the reference's fp32
+        # region-layer logits within 1e-3 (north_star) by default.  Training in plain fp16 does NOT meet 1e-3 end to
+        # end on a random-init network (3.3e-2 at B=64; the fp32 oracle with fp16-rounded storage: 3.7e-2); training in
+        # "mixed" does, at ~0.6 of the throughput (bench.py reports both).
         self.precision = os.environ.get("MCAMD_PRECISION", "auto")
 
     # ---- engine plumbing
@@ -289,12 +292,14 @@ class Darknet(nn.Module):
         prec = self.precision
         if prec == "auto":
             prec = "fp16" if self.training else "mixed"
-        key = (tuple(x.shape), x.device.index, float(self.grad_scale), prec)
+        # "mixed" has two budgets: the training-mode forward amplifies operand rounding of the early blocks (engine.py)
+        for_training = bool(self.training and prec == "mixed")
+        key = (tuple(x.shape), x.device.index, float(self.grad_scale), prec, for_training)
         eng = self._engines.get(key)
         if eng is None:
             if len(self._engines) >= 3:
                 self._engines.pop(next(iter(self._engines)))
-            eng = Engine(self, x.shape[0], x.shape[2], x.shape[3], x.device, self.grad_scale, prec)
+            eng = Engine(self, x.shape[0], x.shape[2], x.shape[3], x.device, self.grad_scale, prec, for_training)
             self._engines[key] = eng
         return eng
 
