@@ -364,6 +364,36 @@ int mcamd_nchw_f32_to_padded_nhwc_f16_split(const float* src, int32_t B, int32_t
                                             void* dst, int32_t dst_ld, int32_t dst_choff, int32_t plane, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Launch plans: a whole forward or backward pass as ONE library call.
+ * The reference executes Darknet.forward as one Python call per torch module (src/nets.py:720-774) and autograd
+ * replays them; here the caller walks its layer list ONCE between mcamd_plan_begin and mcamd_plan_end: every
+ * launch-type entry point above (pack / fold / conv fwd / dgrad / wgrad / bn_coeffs / bn_act fwd + bwd / stem block /
+ * layout conversion / mcamd_stream_wait / mcamd_memset_zero) then RECORDS its arguments -- descriptors copied by
+ * value -- instead of launching, on the recording host thread only.  mcamd_plan_run replays them: same launches, same
+ * order, same streams (bit-identical results), without the per-launch host overhead of a language binding.
+ * A plan holds the raw device pointers it was recorded with: the caller keeps those buffers in place and records a
+ * new plan when one moves.  Argument errors of a recorded call surface from mcamd_plan_run.  Queries
+ * (*_workspace_bytes, tile_info, ...) are never recorded.
+ *   streams  : the hipStream_t's (as void*) the recording may see, slot 0 first; mcamd_plan_run takes the streams to
+ *              replay on in the same slot order (normally the same ones)
+ *   segments : mcamd_plan_mark() closes a segment; mcamd_plan_run(p, lo, hi, ...) replays segments [lo, hi) -- the
+ *              data-parallel reducer is called between segments, when a gradient slice has become final
+ * ------------------------------------------------------------------------- */
+typedef struct mcamd_plan mcamd_plan;
+int mcamd_plan_begin(void* const* streams, int32_t nstreams);
+int32_t mcamd_plan_mark(void);                    /* -> index of the segment that starts here */
+mcamd_plan* mcamd_plan_end(void);                 /* NULL when a recorded call failed (mcamd_last_error) */
+int32_t mcamd_plan_segments(const mcamd_plan* p);
+int32_t mcamd_plan_launches(const mcamd_plan* p); /* recorded calls (a call may launch several kernels) */
+int mcamd_plan_run(mcamd_plan* p, int32_t seg_lo, int32_t seg_hi, void* const* streams, int32_t nstreams);
+void mcamd_plan_destroy(mcamd_plan* p);
+/* `waiter` waits for all work enqueued so far on `signal` (event record + stream wait; the two-stream backward pass
+ * hands weight gradients to its second stream this way).  Recordable. */
+int mcamd_stream_wait(void* waiter_stream, void* signal_stream);
+/* hipMemsetAsync(dst, 0, bytes) -- the zero rows of a filter-pruned layer's weight gradient.  Recordable. */
+int mcamd_memset_zero(void* dst, size_t bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Pruning (reference src/pruning/weightPruning/methods.py).
  * ------------------------------------------------------------------------- */
 /* k-th smallest |w| (0-based, ascending) over `nseg` fp32 tensors -- the order statistic

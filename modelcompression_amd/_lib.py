@@ -118,6 +118,15 @@ SIGNATURES = {
     "mcamd_stem_block_bwd": (C.c_int, [C.POINTER(StemBlockDesc), _P, _SZ, _P]),
     "mcamd_nchw_f32_to_padded_nhwc_f16": (C.c_int, [_P, _I32, _I32, _I32, _I32, _F, _P, _I32, _I32, _P, _P]),
     "mcamd_nchw_f32_to_padded_nhwc_f16_split": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _P]),
+    "mcamd_plan_begin": (C.c_int, [C.POINTER(_P), _I32]),
+    "mcamd_plan_mark": (_I32, []),
+    "mcamd_plan_end": (_P, []),
+    "mcamd_plan_segments": (_I32, [_P]),
+    "mcamd_plan_launches": (_I32, [_P]),
+    "mcamd_plan_run": (C.c_int, [_P, _I32, _I32, C.POINTER(_P), _I32]),
+    "mcamd_plan_destroy": (None, [_P]),
+    "mcamd_stream_wait": (C.c_int, [_P, _P]),
+    "mcamd_memset_zero": (C.c_int, [_P, _SZ, _P]),
     "mcamd_kth_magnitude_workspace_bytes": (_SZ, []),
     "mcamd_kth_magnitude": (C.c_int, [C.POINTER(_P), C.POINTER(_I64), _I32, _I64, _P, _P, _SZ, _P]),
     "mcamd_magnitude_mask": (C.c_int, [_P, _I64, _P, _P, _P]),

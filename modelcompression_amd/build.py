@@ -29,6 +29,7 @@ SOURCES = {
     "conv_wgrad_stem.hip": [],
     "bn_act.hip": [],
     "fold.hip": [],
+    "plan.hip": [],
     "prune.hip": ["-ffp-contract=off"],   # pinned fp32 arithmetic: no FMA contraction
 }
 

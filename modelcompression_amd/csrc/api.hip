@@ -151,6 +151,13 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* w, const f
 
 extern "C" int mcamd_pack_weights(const mcamd_conv_geom* g, const float* w_oihw, const float* mask_oihw,
                                   const mcamd_chan_map* map, void* wp_fwd, void* wp_dgrad, void* stream) {
+    if (mcamd_recording()) {
+        MCAMD_REQUIRE(g, "pack_weights: null geometry");
+        const mcamd_conv_geom g_ = *g;
+        const bool has_map = map != nullptr;
+        const mcamd_chan_map m_ = has_map ? *map : mcamd_chan_map{nullptr, nullptr};
+        return mcamd_rec_push(stream, [=](void* s) { return mcamd_pack_weights(&g_, w_oihw, mask_oihw, has_map ? &m_ : nullptr, wp_fwd, wp_dgrad, s); });
+    }
     if (check_geom(g, "pack_weights")) return MCAMD_EINVAL;
     MCAMD_REQUIRE(w_oihw, "pack_weights: null weights");
     const int* rmap = map ? (const int*)map->rows : nullptr;
@@ -285,6 +292,8 @@ __global__ __launch_bounds__(256) void pack_tiles_kernel(const mcamd_pack_job* j
 }
 
 extern "C" int mcamd_pack_weights_many(const mcamd_pack_job* jobs_dev, int32_t njobs, int64_t total_tiles, void* stream) {
+    if (mcamd_recording())
+        return mcamd_rec_push(stream, [=](void* s) { return mcamd_pack_weights_many(jobs_dev, njobs, total_tiles, s); });
     MCAMD_REQUIRE(jobs_dev && njobs > 0 && total_tiles > 0, "pack_weights_many: empty job table");
     long long grid = total_tiles;
     if (grid > 16384) grid = 16384;
@@ -382,6 +391,12 @@ extern "C" int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int
 
 extern "C" int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const void* wp_fwd, const mcamd_conv_epilogue* epi,
                               void* stream) {
+    if (mcamd_recording()) {
+        MCAMD_REQUIRE(g && epi, "conv_fwd: null geometry / epilogue");
+        const mcamd_conv_geom g_ = *g;
+        const mcamd_conv_epilogue e_ = *epi;
+        return mcamd_rec_push(stream, [=](void* s) { return mcamd_conv_fwd(&g_, x, wp_fwd, &e_, s); });
+    }
     if (check_geom(g, "conv_fwd")) return MCAMD_EINVAL;
     MCAMD_REQUIRE(x && wp_fwd, "conv_fwd: null input");
     IgemmArgs a;
@@ -415,6 +430,12 @@ extern "C" int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const voi
 
 extern "C" int mcamd_conv_dgrad(const mcamd_conv_geom* g, const void* dy, int32_t dy_ld, int32_t dy_choff,
                                 const void* wp_dgrad, const mcamd_conv_epilogue* epi, void* stream) {
+    if (mcamd_recording()) {
+        MCAMD_REQUIRE(g && epi, "conv_dgrad: null geometry / epilogue");
+        const mcamd_conv_geom g_ = *g;
+        const mcamd_conv_epilogue e_ = *epi;
+        return mcamd_rec_push(stream, [=](void* s) { return mcamd_conv_dgrad(&g_, dy, dy_ld, dy_choff, wp_dgrad, &e_, s); });
+    }
     if (check_geom(g, "conv_dgrad")) return MCAMD_EINVAL;
     MCAMD_REQUIRE(!g->stem, "conv_dgrad: the stem layer has no input gradient");
     MCAMD_REQUIRE(dy && wp_dgrad, "conv_dgrad: null input");
@@ -463,6 +484,16 @@ extern "C" size_t mcamd_conv_wgrad_workspace_bytes(const mcamd_conv_geom* g) {
 extern "C" int mcamd_conv_wgrad(const mcamd_conv_geom* g, const void* x, const void* dy, int32_t dy_ld, int32_t dy_choff,
                                 const float* mask_oihw, const mcamd_chan_map* map, float grad_scale, float* dw_oihw,
                                 float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+    if (mcamd_recording()) {
+        MCAMD_REQUIRE(g, "conv_wgrad: null geometry");
+        const mcamd_conv_geom g_ = *g;
+        const bool has_map = map != nullptr;
+        const mcamd_chan_map m_ = has_map ? *map : mcamd_chan_map{nullptr, nullptr};
+        return mcamd_rec_push(stream, [=](void* s) {
+            return mcamd_conv_wgrad(&g_, x, dy, dy_ld, dy_choff, mask_oihw, has_map ? &m_ : nullptr, grad_scale, dw_oihw, dbias,
+                                    workspace, workspace_bytes, s);
+        });
+    }
     if (check_geom(g, "conv_wgrad")) return MCAMD_EINVAL;
     MCAMD_REQUIRE(x && dy && dw_oihw && workspace, "conv_wgrad: null argument");
     MCAMD_REQUIRE(grad_scale > 0.f, "conv_wgrad: grad_scale must be positive");

@@ -738,6 +738,11 @@ extern "C" int mcamd_bn_coeffs_ex(const float* stats, int32_t stats_rows, int32_
                                   float momentum, float eps, int32_t training, float* scale, float* shift,
                                   float* save_mean, float* save_invstd, const int32_t* chan_perm, int32_t ones_channel,
                                   void* stream) {
+    if (mcamd_recording())
+        return mcamd_rec_push(stream, [=](void* s) {
+            return mcamd_bn_coeffs_ex(stats, stats_rows, stats_ld, C, count, gamma, beta, running_mean, running_var, momentum, eps,
+                                      training, scale, shift, save_mean, save_invstd, chan_perm, ones_channel, s);
+        });
     MCAMD_REQUIRE(C > 0 && gamma && beta && running_mean && running_var && scale && shift, "bn_coeffs: null argument");
     MCAMD_REQUIRE(!training || (stats && stats_rows > 0 && stats_ld >= C && count > 0), "bn_coeffs: bad statistics slab");
     MCAMD_REQUIRE(ones_channel < C, "bn_coeffs: ones_channel %d outside the %d channels", ones_channel, C);
@@ -766,6 +771,11 @@ static int check_c(int C, const char* what) {
 }
 
 extern "C" int mcamd_bn_act_fwd(const mcamd_act_desc* d, void* stream) {
+    if (mcamd_recording()) {
+        MCAMD_REQUIRE(d, "bn_act_fwd: null descriptor");
+        const mcamd_act_desc d_ = *d;
+        return mcamd_rec_push(stream, [=](void* s) { return mcamd_bn_act_fwd(&d_, s); });
+    }
     MCAMD_REQUIRE(d && d->y && d->dst && d->scale && d->shift, "bn_act_fwd: null argument");
     MCAMD_REQUIRE(d->C > 0 && d->C % 8 == 0, "bn_act_fwd: channel count %d must be a positive multiple of 8", d->C);
     MCAMD_REQUIRE(d->y_ld % 8 == 0 && d->y_choff % 8 == 0 && d->dst_ld % 8 == 0 && d->dst_choff % 8 == 0 &&
@@ -834,6 +844,11 @@ extern "C" size_t mcamd_bn_act_bwd_workspace_bytes(const mcamd_act_bwd_desc* d) 
 }
 
 extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+    if (mcamd_recording()) {
+        MCAMD_REQUIRE(d, "bn_act_bwd: null descriptor");
+        const mcamd_act_bwd_desc d_ = *d;
+        return mcamd_rec_push(stream, [=](void* s) { return mcamd_bn_act_bwd(&d_, workspace, workspace_bytes, s); });
+    }
     MCAMD_REQUIRE(d && d->y && d->g && d->dy && d->scale && d->shift && d->mean && d->invstd && workspace,
                   "bn_act_bwd: null argument");
     if (check_c(d->C, "bn_act_bwd")) return MCAMD_EINVAL;
@@ -932,6 +947,10 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
 extern "C" int mcamd_nchw_f32_to_padded_nhwc_f16(const float* src, int32_t B, int32_t C, int32_t H, int32_t W, float mul,
                                                  void* dst, int32_t dst_ld, int32_t dst_choff, int32_t* overflow,
                                                  void* stream) {
+    if (mcamd_recording())
+        return mcamd_rec_push(stream, [=](void* s) {
+            return mcamd_nchw_f32_to_padded_nhwc_f16(src, B, C, H, W, mul, dst, dst_ld, dst_choff, overflow, s);
+        });
     MCAMD_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc: bad argument");
     MCAMD_REQUIRE(dst_choff + C <= dst_ld || dst_ld == 4, "nchw_to_nhwc: channel slice exceeds ld");
     MCAMD_REQUIRE((C >= 8) ? (dst_ld % 8 == 0 && dst_choff % 8 == 0) : true, "nchw_to_nhwc: alignment");
@@ -946,6 +965,10 @@ extern "C" int mcamd_nchw_f32_to_padded_nhwc_f16(const float* src, int32_t B, in
 extern "C" int mcamd_nchw_f32_to_padded_nhwc_f16_split(const float* src, int32_t B, int32_t C, int32_t H, int32_t W,
                                                        void* dst, int32_t dst_ld, int32_t dst_choff, int32_t plane,
                                                        void* stream) {
+    if (mcamd_recording())
+        return mcamd_rec_push(stream, [=](void* s) {
+            return mcamd_nchw_f32_to_padded_nhwc_f16_split(src, B, C, H, W, dst, dst_ld, dst_choff, plane, s);
+        });
     MCAMD_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc_split: bad argument");
     MCAMD_REQUIRE(plane >= C && dst_choff + 2 * plane + C <= dst_ld, "nchw_to_nhwc_split: three planes of %d channels, %d apart, exceed ld %d",
                   C, plane, dst_ld);

@@ -59,6 +59,14 @@ struct McamdEnvSlot {
         }                                                                           \
     } while (0)
 
+// Launch plans (plan.hip): while a host thread records, every launch-type entry point appends a by-value copy of its
+// arguments to the plan instead of launching.
+#include <functional>
+struct mcamd_plan;
+extern thread_local mcamd_plan* g_mcamd_rec;
+static inline bool mcamd_recording() { return g_mcamd_rec != nullptr; }
+int mcamd_rec_push(void* stream, std::function<int(void*)> fn);
+
 static inline int round_up_int(int v, int m) { return (v + m - 1) / m * m; }
 static inline long long round_up_ll(long long v, long long m) { return (v + m - 1) / m * m; }
 

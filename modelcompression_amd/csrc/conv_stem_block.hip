@@ -581,6 +581,11 @@ void fill_args(StemBlockArgs& a, const mcamd_stem_block_desc* d) {
 extern "C" size_t mcamd_stem_block_workspace_bytes(void) { return carve().total; }
 
 extern "C" int mcamd_stem_block_fwd(const mcamd_stem_block_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+    if (mcamd_recording()) {
+        MCAMD_REQUIRE(d, "stem_block_fwd: null descriptor");
+        const mcamd_stem_block_desc d_ = *d;
+        return mcamd_rec_push(stream, [=](void* s) { return mcamd_stem_block_fwd(&d_, workspace, workspace_bytes, s); });
+    }
     if (check_desc(d, "stem_block_fwd")) return MCAMD_EINVAL;
     MCAMD_REQUIRE(d->planes == 0 || d->planes == 1 || d->planes == 3, "stem_block_fwd: planes must be 1 or 3 (got %d)", d->planes);
     const int span = d->planes == 3 ? 96 : 32;
@@ -628,6 +633,11 @@ extern "C" int mcamd_stem_block_fwd(const mcamd_stem_block_desc* d, void* worksp
 }
 
 extern "C" int mcamd_stem_block_bwd(const mcamd_stem_block_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+    if (mcamd_recording()) {
+        MCAMD_REQUIRE(d, "stem_block_bwd: null descriptor");
+        const mcamd_stem_block_desc d_ = *d;
+        return mcamd_rec_push(stream, [=](void* s) { return mcamd_stem_block_bwd(&d_, workspace, workspace_bytes, s); });
+    }
     if (check_desc(d, "stem_block_bwd")) return MCAMD_EINVAL;
     MCAMD_REQUIRE(workspace && d->g && d->dw && d->gamma && d->save_mean && d->save_invstd, "stem_block_bwd: null argument");
     MCAMD_REQUIRE(d->cout == 0 || d->cout == 32, "stem_block_bwd: training needs 32 filters (got %d)", d->cout);

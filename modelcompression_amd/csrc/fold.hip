@@ -147,6 +147,11 @@ int check(const mcamd_fold_desc* d, const char* what) {
 }  // namespace
 
 extern "C" int mcamd_fold_weights(const mcamd_fold_desc* d, float* waug, void* stream) {
+    if (mcamd_recording()) {
+        MCAMD_REQUIRE(d, "fold_weights: null descriptor");
+        const mcamd_fold_desc d_ = *d;
+        return mcamd_rec_push(stream, [=](void* s) { return mcamd_fold_weights(&d_, waug, s); });
+    }
     if (check(d, "fold_weights")) return MCAMD_EINVAL;
     MCAMD_REQUIRE(waug, "fold_weights: null output");
     hipLaunchKernelGGL(fold_weights_kernel, dim3(d->n), dim3(256), 0, (hipStream_t)stream, d->w, d->mask, (const int*)d->rows,
@@ -156,6 +161,8 @@ extern "C" int mcamd_fold_weights(const mcamd_fold_desc* d, float* waug, void* s
 }
 
 extern "C" int mcamd_fold_weights_many(const mcamd_fold_job* jobs_dev, int32_t njobs, int64_t total_blocks, void* stream) {
+    if (mcamd_recording())
+        return mcamd_rec_push(stream, [=](void* s) { return mcamd_fold_weights_many(jobs_dev, njobs, total_blocks, s); });
     MCAMD_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "fold_weights_many: empty job table");
     hipLaunchKernelGGL(fold_weights_many_kernel, dim3((int)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
     MCAMD_LAUNCH_CHECK("fold_weights_many");
@@ -164,6 +171,11 @@ extern "C" int mcamd_fold_weights_many(const mcamd_fold_job* jobs_dev, int32_t n
 
 extern "C" int mcamd_unfold_wgrad(const mcamd_fold_desc* d, const float* dwaug, float* dw_oihw, float* prod_dbeta,
                                   float* prod_dgamma, int32_t accumulate, void* stream) {
+    if (mcamd_recording()) {
+        MCAMD_REQUIRE(d, "unfold_wgrad: null descriptor");
+        const mcamd_fold_desc d_ = *d;
+        return mcamd_rec_push(stream, [=](void* s) { return mcamd_unfold_wgrad(&d_, dwaug, dw_oihw, prod_dbeta, prod_dgamma, accumulate, s); });
+    }
     if (check(d, "unfold_wgrad")) return MCAMD_EINVAL;
     MCAMD_REQUIRE(dwaug && dw_oihw && prod_dbeta, "unfold_wgrad: null argument");
     const int dead = d->cin_t - d->cin_k;

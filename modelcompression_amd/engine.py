@@ -129,6 +129,14 @@ class Engine:
         self.overlap_wgrad = os.environ.get("MCAMD_OVERLAP_WGRAD", "1") == "1"
         # every switch is read here, once per engine -- never inside a step
         self.wgrad_chunk = max(1, int(os.environ.get("MCAMD_WGRAD_CHUNK", "1")))
+        # launch plans (csrc/plan.hip): the layer walk of forward / backward is RECORDED once and replayed with one library
+        # call per segment instead of one ctypes call per kernel launch (MCAMD_PLAN=0: the per-launch path; it is also what
+        # a per-kernel timing pass uses).  Plans hold raw pointers: `_plan_epoch` counts re-plannings of the channel layout,
+        # `_ptr_sig()` follows the tensors torch owns.
+        self.use_plan = os.environ.get("MCAMD_PLAN", "1") == "1"
+        self._fwd_plans, self._bwd_plan, self._plan_epoch = {}, None, 0
+        self._logits = self._gout = self._flat = None
+        self._pack_on_side = False
         self.overlap_pack = os.environ.get("MCAMD_OVERLAP_PACK", "auto")
         self.fold_dead = os.environ.get("MCAMD_FOLD_DEAD", "1") == "1"
         self.bn_narrow_on = os.environ.get("MCAMD_BN_NARROW", "1") == "1"
@@ -531,7 +539,7 @@ class Engine:
         # forward() makes the launch stream wait for it in front of the second block (self._pack_event): 7.17 -> 7.10 ms
         # per filter-pruned step.  Dense: the lone re-pack launch gains nothing from it (9.69 vs 9.73 ms), so it stays on
         # the launch stream (MCAMD_OVERLAP_PACK=1 forces the overlap, 0 forbids it).
-        self._pack_event = None
+        self._pack_on_side = False
         side = None
         want = self.overlap_pack
         if (training and self.overlap_wgrad and self.events is None and self.layers[0].fused_stem
@@ -561,8 +569,7 @@ class Engine:
             if self._pack_table is not None:
                 ops.pack_many(*self._pack_table)
             if side is not None:
-                self._pack_event = torch.cuda.Event()
-                self._pack_event.record(side)
+                self._pack_on_side = True      # forward() makes the launch stream wait for the second one before block 2
         self._packed_sig = sig
         self.model._weights_dirty = False
 
@@ -602,6 +609,7 @@ class Engine:
         through `chan_perm`.  Pool / reorg / route keep or compose permutations.  Called when a mask
         object changes (one host sync for the kept counts)."""
         dev = self.device
+        self._plan_epoch += 1            # every recorded plan is stale: buffers / maps / geometries below change
         tperm = {-1: None}               # tensor id -> LongTensor physical position -> original channel (None = identity)
         by_ci = {lay.index: lay for lay in self.layers}
         wbytes = 16
@@ -733,6 +741,18 @@ class Engine:
             return bn.bias.data
         return bn.bias.data - bn.running_mean * bn.weight.data / torch.sqrt(bn.running_var + bn.eps)
 
+    # ------------------------------------------------------------------ launch plans
+    def _ptr_sig(self):
+        """Addresses of every tensor torch owns that a recorded plan holds (parameters, masks, BatchNorm buffers)."""
+        sig = [p.data_ptr() for p in self.params]
+        for lay in self.layers:
+            if lay.bn is not None:
+                sig.append(lay.bn.running_mean.data_ptr())
+                sig.append(lay.bn.running_var.data_ptr())
+            if lay.conv.mask_flag:
+                sig.append(lay.conv.mask.data_ptr())
+        return tuple(sig)
+
     # ------------------------------------------------------------------ forward
     def forward(self, x, training):
         B = self.B
@@ -755,17 +775,43 @@ class Engine:
             ops.nchw_to_padded_split(xs, self.bufs[tin.buf], tin.ld, tin.choff, tin.ps)
         else:
             ops.nchw_to_padded(xs, self.bufs[tin.buf], tin.ld, tin.choff)
-        out = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
+        if self._logits is None:
+            self._logits = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        side = self._get_side_stream() if self._pack_on_side else None
+        if self.use_plan and self.events is None:
+            # one library call replays the recorded layer walk (csrc/plan.hip); recorded again when a pointer moved
+            key = (bool(training), main.cuda_stream, side.cuda_stream if side is not None else 0, self._plan_epoch,
+                   self._ptr_sig())
+            plan = self._fwd_plans.get(bool(training))
+            if plan is None or plan.key != key:
+                plan = ops.Plan([main] + ([side] if side is not None else []))
+                with plan:
+                    self._forward_body(training, main, side)
+                plan.key = key
+                self._fwd_plans[bool(training)] = plan
+            plan.run()
+        else:
+            self._forward_body(training, main, side)
+        last = self.layers[-1]
+        out = self._logits + last.border_map if last.border_map is not None else self._logits.clone()
+        if training:
+            bns = [lay.bn.num_batches_tracked for lay in self.layers if lay.bn is not None]
+            if bns:
+                torch._foreach_add_(bns, 1)
+        return out
+
+    def _forward_body(self, training, main, side):
+        """The layer walk of the forward pass: library calls only (every one of them recordable)."""
+        B = self.B
+        out = self._logits
         for lay in self.layers:
             xin = self.bufs[lay.tin.buf]
-            if lay.li == 1 and getattr(self, "_pack_event", None) is not None:
-                torch.cuda.current_stream(self.device).wait_event(self._pack_event)     # re-pack on the second stream
-                self._pack_event = None
+            if lay.li == 1 and side is not None:
+                ops.stream_wait(main, side)     # the fold + re-pack of the layers behind the first block ran on the second stream
             if lay.is_last:
                 bias = lay.conv.bias.data if lay.conv.bias is not None else None
                 self._timed('fwd', lay, ops.conv_fwd_nchw, lay.geom_f if self.precise else lay.geom_act, xin, lay.wp, out, bias)
-                if lay.border_map is not None:
-                    out += lay.border_map
                 continue
             bn = lay.bn
             if lay.fused_stem or (lay.fused_stem_eval and not training and lay.out_t.ld - lay.out_t.choff >= 32):
@@ -816,11 +862,6 @@ class Engine:
                            lay.slope, lay.mode, self.bufs[t.buf], t.ld, t.choff,
                            self.bufs[t2.buf] if t2 is not None else None,
                            t2.ld if t2 is not None else 0, t2.choff if t2 is not None else 0, border=lay.border)
-        if training:
-            bns = [lay.bn.num_batches_tracked for lay in self.layers if lay.bn is not None]
-            if bns:
-                torch._foreach_add_(bns, 1)
-        return out
 
     # ------------------------------------------------------------------ backward
     def bn_act_bwd_layer(self, lay, g, g_ld, g_choff, g2, g2_ld, g2_choff, dy, dgamma, dbeta, grad_scale):
@@ -840,26 +881,36 @@ class Engine:
         `fence()` returns the stream context in which that slice is visible, to be entered only when a collective is
         really launched -- is called as soon as every kernel writing flat[lo:hi] is enqueued
         (layers finish last-to-first, so the slices walk down from the tail): dp.GradReducer
-        starts its all-reduce buckets there."""
+        starts its all-reduce buckets there.
+        The flat buffer is PERSISTENT (one per engine, the recorded plan holds its address): the views returned here --
+        what p.grad becomes -- are overwritten by the next backward() of this engine."""
         S = self.grad_scale
         # data parallel: every PARAMETER gradient leaves the kernels already divided by the world size (it rides on the
         # 1 / grad_scale factor their finish passes apply anyway), so the summed all-reduce result is the average and no
         # separate 202 MB division pass follows it (dp.attach sets model._grad_div)
         D = S * float(getattr(self.model, "_grad_div", 1.0))
-        # every element is written below (wgrad finish / dgamma / dbeta / dbias): no memset needed
-        flat = torch.empty(self.total_params, dtype=torch.float32, device=self.device)
-        views = [flat[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.params)]
+        if self._flat is None:
+            # every element is written by the kernels (wgrad finish / dgamma / dbeta / dbias): no memset needed
+            self._flat = torch.empty(self.total_params, dtype=torch.float32, device=self.device)
+            self._gout = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
+            self._sizes = [p.numel() for p in self.params]
+        flat = self._flat
+        # fresh view objects per call (autograd's AccumulateGrad adopts a gradient only when nobody else holds it): one
+        # split + a reshape for the 4-d tensors
+        views = [v if p.dim() == 1 else v.view(p.shape) for v, p in zip(flat.split_with_sizes(self._sizes), self.params)]
         gmap = {id(p): v for p, v in zip(self.params, views)}
-        side = main = None
+        self._gout.copy_(grad_out.detach())      # the plan reads the logit gradient from a fixed address
+        main = torch.cuda.current_stream(self.device)
+        side = None
         if self.overlap_wgrad and self.events is None:    # per-kernel timing: one stream, no overlapping launches
-            main = torch.cuda.current_stream(self.device)
             side = self._get_side_stream()
-            flat.record_stream(side)
             # the side stream's split-K slabs must not alias the main stream's: with filter compaction the gather
             # layers run their weight gradient on the main stream while a side-stream one may still be in flight
             if self._side_ws is None or self._side_ws.numel() < self.wgrad_ws.numel():
                 self._side_ws = torch.empty(self.wgrad_ws.numel(), dtype=torch.uint8, device=self.device)
                 self._side_ws.record_stream(side)
+                self._plan_epoch += 1
+
         def fence():
             """Stream context in which a collective over final slices may be enqueued: this block's slice is written from
             both streams (dgamma / dbeta and the gather layers' dW on the main one, dW on the side one), so the side stream
@@ -892,6 +943,35 @@ class Engine:
                 with fence():
                     on_ready(flat, lay.p_lo, lay.p_hi)
 
+        if self.use_plan and self.events is None:
+            key = (main.cuda_stream, side.cuda_stream if side is not None else 0, D, self._plan_epoch, self._ptr_sig())
+            plan = self._bwd_plan
+            if plan is None or plan.key != key:
+                plan = ops.Plan([main] + ([side] if side is not None else []))
+                seg_lays = [[]]
+
+                def close_segment(lay):      # the block's slice of the flat buffer is final once this segment is enqueued
+                    seg_lays[-1].append(lay)
+                    plan.mark()
+                    seg_lays.append([])
+                with plan:
+                    self._backward_body(gmap, main, side, S, D, close_segment)
+                plan.key, plan.seg_lays = key, seg_lays
+                self._bwd_plan = plan
+            if on_ready is None:
+                plan.run()
+            else:
+                for si in range(plan.segments):
+                    plan.run(si, si + 1)
+                    for lay in plan.seg_lays[si]:
+                        ready(lay)
+        else:
+            self._backward_body(gmap, main, side, S, D, ready)
+        return flat, views
+
+    def _backward_body(self, gmap, main, side, S, D, ready):
+        """The layer walk of the backward pass: library calls only (recordable); `ready(lay)` after the last launch that
+        writes block `lay`'s slice of the flat gradient."""
         # Weight gradients go to the second stream in groups of `chunk` blocks (MCAMD_WGRAD_CHUNK, default 1 = each block
         # at once).  Every hand-over is an event record in the launch stream's queue plus a cross-queue wait; grouping 2-3
         # blocks per hand-over measured the same (9.63 / 9.64 / 9.64 ms per dense step), 4 and 6 slower (9.71 / 9.75: the
@@ -902,9 +982,7 @@ class Engine:
         def flush():
             if not pending:
                 return
-            ev = torch.cuda.Event()
-            ev.record(main)
-            side.wait_event(ev)
+            ops.stream_wait(side, main)           # dY of these blocks is complete on the launch stream
             with torch.cuda.stream(side):
                 for fn, _ in pending:
                     fn(self._side_ws)
@@ -925,7 +1003,7 @@ class Engine:
                 ready(lay)
                 continue
             if lay.is_last:
-                ops.nchw_to_padded(grad_out.detach().contiguous().float(), lay.dy, lay.cout_p, 0, S, overflow=self.overflow)
+                ops.nchw_to_padded(self._gout, lay.dy, lay.cout_p, 0, S, overflow=self.overflow)
             else:
                 cons = self.consumer_of[lay.out_id]
                 t = lay.out_t
@@ -944,7 +1022,7 @@ class Engine:
                     # column expands to the dead inputs) and to dbeta of the producer's dead channels (csrc/fold.hip)
                     gw, prod = gmap[id(lay.conv.weight)], lay.fold
                     if lay.perm is not None:
-                        gw.zero_()
+                        ops.memset_zero(gw)
                     self._timed('wgrad', lay, ops.conv_wgrad, lay.geom_act, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
                                 lay.dwaug, None, D, dbias, ws)
                     ops.unfold_wgrad(lay.conv.weight.data, mask, lay.g_rows, lay.g_cols, prod.bn.bias.data, prod.slope, lay.n_act,
@@ -955,7 +1033,7 @@ class Engine:
                     # removed filters are zero (as `grad * mask` makes them in the reference): zeroed here, not computed
                     gw = gmap[id(lay.conv.weight)]
                     if lay.perm is not None:
-                        gw.zero_()
+                        ops.memset_zero(gw)
                     self._timed('wgrad', lay, ops.conv_wgrad, lay.geom_act, self.bufs[lay.tin.buf], lay.dy, lay.cout_p, 0,
                                 gw, mask, D, dbias, ws, rows=lay.g_rows, cols=lay.g_cols)
                 else:
@@ -977,5 +1055,4 @@ class Engine:
                             lay.tin.choff, overflow=self.overflow)
         if side is not None:
             flush()
-            main.wait_stream(side)
-        return flat, views
+            ops.stream_wait(main, side)

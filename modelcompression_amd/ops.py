@@ -375,6 +375,61 @@ def nchw_to_padded_split(src, dst, dst_ld, dst_choff, plane):
                                                           stream_ptr()), "mcamd_nchw_f32_to_padded_nhwc_f16_split")
 
 
+# ------------------------------------------------------------------ launch plans
+class Plan:
+    """A recorded sequence of library calls (include/mcamd.h, "Launch plans"), replayed with one call per segment."""
+
+    def __init__(self, streams):
+        self.streams = list(streams)
+        self._arr = (C.c_void_p * len(self.streams))(*[s.cuda_stream for s in self.streams])
+        self.handle = None
+        self.key = None
+        self.keep = None          # whatever must stay alive while the plan holds its pointers
+
+    def __enter__(self):
+        check(L.lib().mcamd_plan_begin(self._arr, len(self.streams)), "mcamd_plan_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        h = L.lib().mcamd_plan_end()
+        if et is not None:
+            if h:
+                L.lib().mcamd_plan_destroy(h)
+            return False
+        if not h:
+            raise L.McamdError("recording a launch plan failed: %s" % L.lib().mcamd_last_error().decode())
+        self.handle = h
+        self.segments = int(L.lib().mcamd_plan_segments(h))
+        self.launches = int(L.lib().mcamd_plan_launches(h))
+        return False
+
+    def mark(self):
+        return int(L.lib().mcamd_plan_mark())
+
+    def run(self, lo=0, hi=None):
+        check(L.lib().mcamd_plan_run(self.handle, lo, self.segments if hi is None else hi, self._arr, len(self.streams)),
+              "mcamd_plan_run")
+
+    def __del__(self):
+        h, self.handle = self.handle, None
+        if h:
+            try:
+                L.lib().mcamd_plan_destroy(h)
+            except Exception:
+                pass
+
+
+def stream_wait(waiter, signal):
+    """`waiter` (torch stream) waits for everything enqueued so far on `signal`.  Recordable."""
+    check(L.lib().mcamd_stream_wait(C.c_void_p(waiter.cuda_stream), C.c_void_p(signal.cuda_stream)), "mcamd_stream_wait")
+
+
+def memset_zero(t):
+    """Zero a contiguous tensor on the current stream through the library (recordable, unlike Tensor.zero_())."""
+    assert t.is_contiguous()
+    check(L.lib().mcamd_memset_zero(ptr(t), t.numel() * t.element_size(), stream_ptr()), "mcamd_memset_zero")
+
+
 # ------------------------------------------------------------------ pruning
 def kth_magnitude(tensors, k):
     """-> device fp32[2] = (s[k], s[min(k+1, n-1)]) of the ascending |w| over all tensors."""

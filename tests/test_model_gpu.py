@@ -679,9 +679,25 @@ def test_training_step_is_bit_reproducible(dev, masks, B):
         runs.append((out.detach().clone(), m._last_flat_grad.clone()))
     eng = list(m._engines.values())[0]
     assert eng.overlap_wgrad and eng.layers[0].fused_stem
+    assert eng.use_plan and eng._bwd_plan is not None and eng._bwd_plan.launches > 60 and eng._fwd_plans[True].launches > 40
     if masks:
         assert any(lay.fold is not None for lay in eng.layers)
     assert bool(torch.isfinite(runs[0][1]).all())
+    # the recorded launch plan (one library call per pass, csrc/plan.hip) replays exactly the launches the per-launch
+    # path makes: a fresh engine with MCAMD_PLAN=0 must give the same bits
+    os.environ["MCAMD_PLAN"] = "0"
+    try:
+        m._engines = {}
+        m.load_state_dict(state)
+        out = m(x)
+        m.zero_grad()
+        out.float().mean().backward()
+        eng0 = list(m._engines.values())[0]
+        assert not eng0.use_plan and eng0._bwd_plan is None
+        runs.append((out.detach().clone(), m._last_flat_grad.clone()))
+    finally:
+        os.environ.pop("MCAMD_PLAN", None)
+        m._engines = {}
     for o, gflat in runs[1:]:
         assert torch.equal(o, runs[0][0]), "logits differ between identical steps"
         assert torch.equal(gflat, runs[0][1]), "gradients differ between identical steps: %d of %d elements" % (

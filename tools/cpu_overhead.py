@@ -1,7 +1,9 @@
 """Is the training step GPU-bound or launch-bound?  Time the Python loop that ENQUEUES K steps (no synchronisation inside)
 against the time until the GPU has finished them: enqueue << total means the GPU is the bottleneck and the host runs ahead.
 
-    python tools/cpu_overhead.py [dense|filter40] [steps]"""
+    python tools/cpu_overhead.py [dense|filter40] [steps] [batch]
+
+MCAMD_PLAN=0 gives the per-launch path (one ctypes call per kernel launch) for comparison with the recorded launch plans."""
 import os
 import sys
 import time
@@ -20,7 +22,7 @@ model.to(dev).train()
 if wl == "filter40":
     from modelcompression_amd.pruning.weightPruning.methods import quick_filter_prune
     model.set_masks(quick_filter_prune(model, 40.0))
-B = 64
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 if os.environ.get("MCAMD_DP_REHEARSE", "0") == "1":      # the data-parallel machinery with one rank (dp.rehearsal)
     from modelcompression_amd import dp
     dp.init_from_env()
@@ -46,5 +48,8 @@ for _ in range(K):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print("%s: host enqueue %.2f ms/step, until the GPU is done %.2f ms/step (%.0f %% of the time the host was ahead)" % (
-    wl, (t1 - t0) / K * 1e3, (t2 - t0) / K * 1e3, 100 * (1 - (t1 - t0) / (t2 - t0))))
+eng = list(model._engines.values())[0]
+print("%s B=%d plan=%s: host enqueue %.2f ms/step, until the GPU is done %.2f ms/step (%.0f %% of the time the host was ahead)%s" % (
+    wl, B, eng.use_plan, (t1 - t0) / K * 1e3, (t2 - t0) / K * 1e3, 100 * (1 - (t1 - t0) / (t2 - t0)),
+    " | recorded calls: forward %d, backward %d in %d segments" % (eng._fwd_plans[True].launches, eng._bwd_plan.launches,
+                                                                 eng._bwd_plan.segments) if eng.use_plan else ""))
