@@ -889,7 +889,7 @@ class Engine:
         # 1 / grad_scale factor their finish passes apply anyway), so the summed all-reduce result is the average and no
         # separate 202 MB division pass follows it (dp.attach sets model._grad_div)
         D = S * float(getattr(self.model, "_grad_div", 1.0))
-        if self._flat is None:
+        if self._flat is None or os.environ.get("MCAMD_DBG_FRESH_FLAT") == "1":
             # every element is written by the kernels (wgrad finish / dgamma / dbeta / dbias): no memset needed
             self._flat = torch.empty(self.total_params, dtype=torch.float32, device=self.device)
             self._gout = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)

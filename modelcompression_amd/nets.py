@@ -198,10 +198,16 @@ class EmptyModule(nn.Module):
 # ----------------------------------------------------------------------------- autograd bridge
 class _DarknetFn(torch.autograd.Function):
     """logits = engine.forward(x); backward hands every parameter its gradient as a view of one
-    flat fp32 buffer (bucket-free all-reduce for data parallel training)."""
+    flat fp32 buffer (bucket-free all-reduce for data parallel training).
+
+    The 134 parameters are NOT inputs of this node: one `anchor` tensor is, so that autograd calls backward() at all, and
+    backward() stores the gradients itself -- `p.grad = view` (or `p.grad += view` when a gradient is already there: the
+    accumulation semantics of loss.backward()).  134 AccumulateGrad nodes and a 134-tensor argument tuple per step cost
+    0.7 ms of host time (tools/host_profile.py), a third of a step's enqueue time.  What this gives up: tensor hooks on
+    the parameters and torch.autograd.grad(loss, params) -- neither is used on the reference's path (train.py:224-235)."""
 
     @staticmethod
-    def forward(ctx, model, engine, training, x, *params):
+    def forward(ctx, model, engine, training, x, anchor):
         out = engine.forward(x, training)
         ctx.model, ctx.engine, ctx.serial, ctx.training = model, engine, engine.serial, training
         return out
@@ -215,12 +221,20 @@ class _DarknetFn(torch.autograd.Function):
             raise McamdError("backward through an eval-mode forward is not supported; call model.train()")
         if eng.serial != ctx.serial:
             raise McamdError("backward() must follow the forward() it belongs to (activations are kept in place)")
+        # gradients already present (no zero_grad() since the last backward) are accumulated into, as autograd would; they
+        # may alias the engine's persistent flat buffer, so they are saved first (rare path)
+        prev = [(i, p.grad.clone()) for i, p in enumerate(eng.params) if p.grad is not None]
         flat, views = eng.backward(gout, on_ready=ctx.model._grad_ready_hook)
         ctx.model._last_flat_grad = flat
         hook = ctx.model._grad_hook
         if hook is not None:
             hook(flat)
-        return (None, None, None, None) + tuple(views)
+        for i, g in prev:
+            views[i].add_(g)
+        for p, v in zip(eng.params, views):
+            if p.requires_grad:
+                p.grad = v
+        return None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------- Darknet
@@ -251,6 +265,7 @@ class Darknet(nn.Module):
         self._grad_hook = None          # callable(flat_grad) run at the end of backward (data parallel)
         self._grad_ready_hook = None    # callable(flat_grad, lo, hi[, fence]): that slice is final (overlapped all-reduce; Engine.backward)
         self._last_flat_grad = None
+        self._anchor = None             # the one differentiable input of the autograd node (see _DarknetFn)
         self.grad_scale = 256.0         # fp16 gradient scaling inside the engine, undone in fp32
         # Operand precision of the forward convolutions (engine.py): "fp16" (throughput), "fp16x3" (split hi/lo
         # operands, three fp16 MFMA products per multiply), "mixed" (split except on the costliest blocks the 1e-3
@@ -310,8 +325,11 @@ class Darknet(nn.Module):
             raise McamdError("Darknet.forward needs a CUDA (MI355X) tensor: modelcompression_amd has no CPU path "
                              "(the CPU restatement lives in oracle/ and is test infrastructure)")
         eng = self._engine_for(x)
-        params = tuple(self.parameters())
-        return _DarknetFn.apply(self, eng, self.training, x, *params)
+        if self._anchor is None or self._anchor.device != x.device:
+            self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
+        if not torch.is_grad_enabled():
+            return eng.forward(x, self.training)
+        return _DarknetFn.apply(self, eng, self.training, x, self._anchor)
 
     def print_network(self):
         print_cfg(self.blocks)

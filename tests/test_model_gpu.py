@@ -708,3 +708,24 @@ def test_cpu_tensor_raises(dev):
     m, _, _ = _mini_model(dev)
     with pytest.raises(RuntimeError):
         m(torch.rand(1, 3, 64, 64))
+
+
+def test_backward_accumulates_into_existing_gradients(dev):
+    """loss.backward() semantics (reference train.py:233 relies on zero_grad() before it, torch accumulates otherwise): the
+    engine writes one persistent flat gradient buffer and stores p.grad itself (nets._DarknetFn); a second backward without
+    zero_grad() must add to the gradients that are there -- exactly twice the first ones for the same input."""
+    m, _, _ = _mini_model(dev)
+    m.train()
+    g = torch.Generator().manual_seed(5)
+    x, gout = torch.rand(2, 3, 64, 64, generator=g).to(dev), torch.randn(2, 125, 16, 16, generator=g).to(dev)
+    m(x).backward(gout)
+    first = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m(x).backward(gout)
+    for n, p in m.named_parameters():
+        assert torch.equal(p.grad, 2 * first[n]), n
+    m.zero_grad()
+    m(x).backward(gout)
+    for n, p in m.named_parameters():
+        assert torch.equal(p.grad, first[n]), n
+    with torch.no_grad():
+        assert not m(x).requires_grad
