@@ -48,6 +48,19 @@ for _ in range(K):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
+# the host cost of ONE step without back-pressure: synchronise, then time only the Python side of a step going into an
+# EMPTY hardware queue.  (The back-to-back loop above measures something else once the host is ahead: hipLaunchKernel
+# blocks while the queue is full, so its "enqueue" time follows the GPU's step time -- 3.8 ms at B=64, 2.4 ms at B=32 and
+# at B=2, with or without launch plans.)
+es = []
+for _ in range(20):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()
+    es.append((time.perf_counter() - t0) * 1e3)
+torch.cuda.synchronize()
+es.sort()
+print("%s B=%d: enqueue of one step into an empty queue: median %.2f ms, min %.2f ms" % (wl, B, es[len(es) // 2], es[0]))
 eng = list(model._engines.values())[0]
 print("%s B=%d plan=%s: host enqueue %.2f ms/step, until the GPU is done %.2f ms/step (%.0f %% of the time the host was ahead)%s" % (
     wl, B, eng.use_plan, (t1 - t0) / K * 1e3, (t2 - t0) / K * 1e3, 100 * (1 - (t1 - t0) / (t2 - t0)),

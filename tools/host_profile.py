@@ -41,6 +41,19 @@ for _ in range(10):
     torch.cuda.synchronize()
     ts.append((time.perf_counter() - t0) * 1e3)
 print("synchronised step times (ms):", " ".join("%.2f" % t for t in ts))
+# enqueue time of ONE step into an EMPTY queue (synchronise, then time only the Python side): the host cost of a step
+# without back-pressure from the hardware queue (a host that runs ahead blocks in hipLaunchKernel once the queue is full,
+# which a back-to-back loop counts as "enqueue time")
+es = []
+for _ in range(20):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()
+    es.append((time.perf_counter() - t0) * 1e3)
+torch.cuda.synchronize()
+es.sort()
+print("enqueue of one step into an empty queue: median %.3f ms, min %.3f ms (plan=%s)" % (
+    es[len(es) // 2], es[0], list(model._engines.values())[0].use_plan))
 pr = cProfile.Profile()
 pr.enable()
 t0 = time.perf_counter()
