@@ -254,6 +254,32 @@ struct ActBwdArgs {
 };
 
 // PHASE 0: per-channel sums of g_z and g_z*xhat -> slab.  PHASE 1: dy -> padded NHWC.
+// Pass 0 of the BatchNorm backward kernels: every thread holds partial sums sb[8] / sg[8] of its 8 channels; threads t and
+// t + CH (+ 2 CH ...) hold the same channel group.  The block's sums go to slab rows (2 block, 2 block + 1) in a fixed
+// order (deterministic).  LDS scratch [16 values][256 threads] with a row pitch of 264 floats: writes are lane-consecutive
+// and the reads of 64 consecutive channels (8 groups x 8 values) hit 64 distinct banks ((8 value + group) mod 64).  The
+// layout of rounds 1-2, red[thread][16], put the 64 lanes of a store on 4 banks: SQ_LDS_BANK_CONFLICT 443 M cycles per 16
+// launches of bn_plain_bwd_kernel<0>, the largest count in the profile (profiles/r02c_pmc_per_kernel.json); the slab
+// stores were 4-byte pieces at a 32-byte stride and are whole lines now.
+__device__ __forceinline__ void block_partials_to_slab(const float (&sb)[8], const float (&sg)[8], int CH, float* slab, int C) {
+    constexpr int PITCH = 264;
+    __shared__ float red[16 * PITCH];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        red[i * PITCH + threadIdx.x] = sb[i];
+        red[(8 + i) * PITCH + threadIdx.x] = sg[i];
+    }
+    __syncthreads();
+    const int reps = 256 / CH;
+    for (int o = threadIdx.x; o < 16 * CH; o += 256) {
+        const int which = o / (8 * CH), c = o - which * 8 * CH;      // c = channel inside the block's C = 8 CH channels
+        const int ch = c >> 3, v = which * 8 + (c & 7);
+        float s = 0.f;
+        for (int k = 0; k < reps; ++k) s += red[v * PITCH + k * CH + ch];
+        slab[((long long)blockIdx.x * 2 + which) * C + c] = s;
+    }
+}
+
 template <int MODE, int PHASE, bool Y32>
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(ActBwdArgs a) {
     constexpr int NP = MODE == MCAMD_DST_PLAIN ? 1 : 4;
@@ -378,20 +404,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(ActBwdArgs a) {
     if (PHASE == 1 && sat && a.overflow) atomicOr(a.overflow, 1);
 
     if (PHASE == 0) {
-        __shared__ float red[256 * 16];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            red[threadIdx.x * 16 + i] = sb[i];
-            red[threadIdx.x * 16 + 8 + i] = sg[i];
-        }
-        __syncthreads();
-        const int reps = 256 / CH;
-        for (int o = threadIdx.x; o < 16 * CH; o += 256) {
-            int ch = o % CH, v = o / CH;
-            float s = 0.f;
-            for (int k = 0; k < reps; ++k) s += red[(k * CH + ch) * 16 + v];
-            a.slab[((long long)blockIdx.x * 2 + (v >> 3)) * a.C + ch * 8 + (v & 7)] = s;
-        }
+        block_partials_to_slab(sb, sg, CH, a.slab, a.C);
     }
 }
 
@@ -469,20 +482,7 @@ __global__ __launch_bounds__(256) void bn_plain_bwd_kernel(ActBwdArgs a) {
     }
     if (PHASE == 1 && satmax > 65504.f && a.overflow) atomicOr(a.overflow, 1);
     if (PHASE == 0) {
-        __shared__ float red[256 * 16];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            red[threadIdx.x * 16 + i] = sb[i];
-            red[threadIdx.x * 16 + 8 + i] = sg[i];
-        }
-        __syncthreads();
-        const int reps = 256 / CH;
-        for (int o = threadIdx.x; o < 16 * CH; o += 256) {
-            int ch = o % CH, v = o / CH;
-            float s = 0.f;
-            for (int k = 0; k < reps; ++k) s += red[(k * CH + ch) * 16 + v];
-            a.slab[((long long)blockIdx.x * 2 + (v >> 3)) * a.C + ch * 8 + (v & 7)] = s;
-        }
+        block_partials_to_slab(sb, sg, CH, a.slab, a.C);
     }
 }
 
@@ -636,20 +636,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(ActBwdArgs a) {
     }
     if (PHASE == 1 && satmax > 65504.f && a.overflow) atomicOr(a.overflow, 1);
     if (PHASE == 0) {
-        __shared__ float red[256 * 16];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            red[threadIdx.x * 16 + i] = sb[i];
-            red[threadIdx.x * 16 + 8 + i] = sg[i];
-        }
-        __syncthreads();
-        const int reps = 256 / CH;
-        for (int o = threadIdx.x; o < 16 * CH; o += 256) {
-            int ch = o % CH, v = o / CH;
-            float s = 0.f;
-            for (int k = 0; k < reps; ++k) s += red[(k * CH + ch) * 16 + v];
-            a.slab[((long long)blockIdx.x * 2 + (v >> 3)) * a.C + ch * 8 + (v & 7)] = s;
-        }
+        block_partials_to_slab(sb, sg, CH, a.slab, a.C);
     }
 }
 

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_final
 rm -rf $OUT && mkdir -p $OUT
 export MCAMD_OVERLAP_WGRAD=0
-CMD="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+CMD="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-tolerance-mode"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD --layer-table $OUT/layer_table.txt > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/write.log 2>&1
