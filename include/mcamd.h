@@ -103,7 +103,9 @@ int32_t mcamd_conv_stats_rows_mode(const mcamd_conv_geom* g, int32_t mode);
 /* Workgroup tile {BM, BN, BK, kernel} the forward (dgrad == 0) or dgrad launch of this geometry uses:
  * kernel 0 = igemm_kernel<BM,BN,..,BK,..> (one tap per K chunk),
  * 2 = igemm_pp_kernel (ping-pong, one workgroup per CU), 1 = stem_fwd_kernel (first layer, no LDS staging),
- * 4 = small3x3_kernel (narrow 3x3 layers on huge images, no LDS staging). */
+ * 4 = small3x3_kernel (narrow 3x3 layers on huge images, no LDS staging), 5 = win3x3_kernel (rolling LDS window),
+ * 6 = wres_kernel (3x3 layers with one 64-channel input block: weights resident in registers, one activation window per
+ * M tile of 128 padded pixels). */
 int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int32_t out[4]);
 
 /* Packed-weight sizes (elements of fp16) for a geometry. */

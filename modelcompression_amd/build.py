@@ -25,6 +25,7 @@ SOURCES = {
     "conv_stem_block.hip": [],
     "conv_small.hip": [],
     "conv_win.hip": [],
+    "conv_wres.hip": [],
     "conv_wgrad.hip": [],
     "conv_wgrad_stem.hip": [],
     "bn_act.hip": [],

@@ -362,6 +362,8 @@ static int fill_epilogue(IgemmArgs& a, const mcamd_conv_epilogue* e, int n_out, 
 extern "C" int32_t mcamd_conv_stats_rows(const mcamd_conv_geom* g) {
     if (!g) return 0;
     if (mcamd_stem_direct_ok(g->stem, g->cout, MCAMD_EPI_RAW_F16)) return mcamd_stem_rows((long long)g->B * g->H * g->W);
+    if (mcamd_wres_ok(g->ksize, g->stem, g->cout, cin_tap_of(g), ntaps_of(g) * cin_tap_of(g), g->B, g->H, g->W, MCAMD_EPI_RAW_F16))
+        return mcamd_wres_rows(g->cout, g->B, g->H, g->W);
     return mcamd_igemm_rows((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g), ntaps_of(g) * cin_tap_of(g));
 }
 
@@ -378,6 +380,10 @@ extern "C" int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int
     out[3] = 0;
     if (!dgrad && mcamd_stem_direct_ok(g->stem, g->cout, MCAMD_EPI_RAW_F16)) {
         out[0] = 32, out[1] = g->cout, out[2] = 48, out[3] = 1;   // stem_fwd_kernel (conv_stem.hip)
+        return MCAMD_OK;
+    }
+    if (!dgrad && mcamd_wres_ok(g->ksize, g->stem, g->cout, cin_tap_of(g), ntaps_of(g) * cin_tap_of(g), g->B, g->H, g->W, MCAMD_EPI_RAW_F16)) {
+        out[0] = 128, out[1] = 128, out[2] = 64, out[3] = 6;   // wres_kernel (conv_wres.hip): weights resident in registers
         return MCAMD_OK;
     }
     if (dgrad && mcamd_win3x3_shape((long long)g->B * g->H * g->W, g->cin, cout_p_of(g), g->ksize * g->ksize * cout_p_of(g), g->W)) {
@@ -416,8 +422,11 @@ extern "C" int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const voi
     a.ktot = a.ntaps * a.cin_tap;
     fill_taps(g->ksize, g->stem, a.x_row_stride, g->x_ld, a.tap_off);
     const bool stem_direct = epi && mcamd_stem_direct_ok(g->stem, g->cout, epi->mode);
-    if (fill_epilogue(a, epi, g->cout, a.M, a.cin_tap, a.ktot, "conv_fwd", stem_direct ? mcamd_stem_rows(a.M) : -1))
+    const bool wres = epi && mcamd_wres_ok(g->ksize, g->stem, g->cout, a.cin_tap, a.ktot, g->B, g->H, g->W, epi->mode);
+    if (fill_epilogue(a, epi, g->cout, a.M, a.cin_tap, a.ktot, "conv_fwd",
+                      stem_direct ? mcamd_stem_rows(a.M) : (wres ? mcamd_wres_rows(g->cout, g->B, g->H, g->W) : -1)))
         return MCAMD_EINVAL;
+    if (wres) return mcamd_wres_launch(a, g->B, (hipStream_t)stream);
     if (stem_direct) {       // conv_stem.hip: weights in registers, image fragments straight from global memory
         StemArgs q;
         q.x = a.x, q.w = a.w, q.y = (half_t*)a.y, q.stats = a.stats;

@@ -94,6 +94,10 @@ bool mcamd_small3x3_ok(long long M, int n, int cin_tap, int ktot);   // conv_sma
 int mcamd_small3x3_rows(long long M);
 int mcamd_small3x3_launch(const IgemmArgs& a, hipStream_t st);
 
+bool mcamd_wres_ok(int ksize, int stem, int n, int cin_tap, int ktot, int B, int H, int W, int mode);   // conv_wres.hip
+int mcamd_wres_rows(int n, int B, int H, int W);
+int mcamd_wres_launch(IgemmArgs& a, int B, hipStream_t st);
+
 bool mcamd_stem_direct_ok(int stem, int cout, int mode);
 int mcamd_stem_rows(long long M);
 int mcamd_stem_launch(const StemArgs& a, int cout, hipStream_t st);

@@ -636,3 +636,44 @@ def test_filter_mask_count_zeros_residual(dev):
     assert ops.count_zeros([wz, torch.zeros(7, device=dev)]) == 2 * 36 + 7
     assert ops.masked_residual([wz], [ref.to(dev)]) == 0.0
     assert ops.masked_residual([w.to(dev)], [ref.to(dev)]) > 0.0
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(3, 40, 36, 64, 128), (2, 27, 104, 48, 256), (5, 21, 13, 64, 192), (2, 16, 112, 56, 136)])
+def test_wres_kernel_vs_igemm(dev, setenv, B, H, W, cin, cout):
+    """wres_kernel (conv_wres.hip: weights resident in registers, one activation window per tile of 128 PADDED pixels;
+    conv3 / conv5-shaped forward launches, one 64-channel input block) accumulates over K in igemm_kernel's order with the
+    same MFMA shape: raw fp16 outputs BIT-identical to igemm_kernel's (MCAMD_WRES=0), BatchNorm partial sums equal up to the
+    summation order of the slab, halo pixels never stored (the output buffer is poisoned first), ragged last tile, channel
+    slices, the padded BN + LeakyReLU epilogue of the eval path, repeated launches reproducible."""
+    x, w = _rand_case(B, H, W, cin, cout, 3, seed=21)
+    xb, ld = to_padded(x.to(dev))
+    g = ops.geom(B, H, W, 3, cin, cout, ld)
+    wp, _ = ops.pack_weights(g, w.to(dev).contiguous())
+    y_ld = cout + 8
+
+    def run():
+        y = torch.full((B * H * W * y_ld,), 7.0, dtype=torch.float16, device=dev)
+        stats = torch.full((ops.stats_rows(g), 2, ops.round_up(cout, 256)), float("nan"), dtype=torch.float32, device=dev)
+        ops.conv_fwd_raw(g, xb, wp, y, y_ld, 8, stats)
+        return y, stats.sum(0), ops.tile_info(g)
+    setenv("MCAMD_WRES", "0")
+    y0, s0, t0 = run()
+    assert t0[3] != 6
+    setenv("MCAMD_WRES", "1")
+    setenv("MCAMD_WRES_MIN_ROUNDS", "0")
+    for rep in range(3):
+        y1, s1, t1 = run()
+        assert t1[3] == 6
+        assert torch.equal(y1, y0), "wres raw output differs from igemm_kernel (rep %d): %d elements" % (rep, int((y1 != y0).sum()))
+        assert torch.allclose(s1[:, :cout], s0[:, :cout], rtol=1e-4, atol=1e-2)
+    ref = F.conv2d(q16(x), q16(w), None, 1, 1)
+    assert rel_l2(raw_to_nchw(y1, B, H, W, y_ld, cout, 8), ref) < TOL
+    assert float((y1.view(-1, y_ld)[:, :8] - 7.0).abs().max()) == 0.0           # the channels in front of the slice are untouched
+    # eval epilogue: BN + LeakyReLU into a padded buffer, halo stays zero
+    scale, shift = torch.rand(cout) + 0.5, torch.randn(cout) * 0.2
+    dst = ops.alloc_padded(B, H, W, 320, dev)
+    ops.conv_fwd_padded(g, xb, wp, dst, 320, 32, scale.to(dev), shift.to(dev), 0.1)
+    got = padded_to_nchw(dst, B, H, W, 320, cout, 32)
+    refp = F.leaky_relu(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), 0.1)
+    assert rel_l2(got, refp) < TOL
+    assert halo_is_zero(dst, B, H, W, 320)
