@@ -245,6 +245,13 @@ class Engine:
         # (not in training: there the first block's operand rounding alone costs 1.9e-2 on the logits, MIXED_BUDGET_TRAIN)
         self.stem = (cin0 == 3 and first_k == 3) and (not self.precise or (self.precision == "mixed" and stem_block_ok
                                                                           and not self.for_training))
+        # "mixed" in training: the first block multiplies split operands through the generic kernels in the FORWARD pass, but
+        # its BACKWARD pass is the fused first block's (plain fp16 operands, as every backward in every mode): that one
+        # recomputes the block from the NHWC4 image, so the block's fp32 raw output (1.4 GB at B=64) is read once by the
+        # activation pass and never again, and its 0.7 GB dY never exists.  The fused forward runs too, into a scratch
+        # output, only to fill the workspace its backward reads (Gram sums) and its own self-consistent coefficients.
+        self.stem_shadow = bool(self.precise and self.for_training and not self.stem and stem_block_ok
+                                and os.environ.get("MCAMD_STEM_SHADOW", "1") == "1")
         ld0 = 4 if self.stem else ops.round_up(cin0 * planes, 32)
         place[-1] = _T(new_buf(B, H0, W0, ld0), ld0, 0, cin0, H0, W0, cin0 if (self.precise and not self.stem) else 0)
         materialized = set()
@@ -359,6 +366,9 @@ class Engine:
                     lay.level = 3
         f32 = dict(dtype=torch.float32, device=dev)
         wbytes = 0
+
+        def li_is_first(l):
+            return l.li == 0
         for lay in self.layers:
             g = lay.geom
             # forward geometry: the K-concatenated problem [x_hi | x_lo | x_hi] x [w_hi | w_hi | w_lo]
@@ -380,7 +390,16 @@ class Engine:
             lay.fused_stem_eval = bool(lay.stem and lay.bn is not None and lay.mode == L.DST_POOL and lay.out2_id is None
                                        and lay.cout in (8, 16, 24) and lay.W % 32 == 0 and lay.H % 2 == 0 and lay.border is None
                                        and os.environ.get("MCAMD_STEM_FUSED", "1") == "1")
-            lay.dy = None if lay.fused_stem else ops.alloc_padded(B, lay.H, lay.W, lay.cout_p, dev)
+            lay.stem_shadow = bool(li_is_first(lay) and self.stem_shadow and lay.bn is not None and lay.mode == L.DST_POOL
+                                   and lay.out2_id is None and lay.cout == 32 and lay.border is None)
+            if lay.stem_shadow:
+                lay.sh_img = ops.alloc_padded(B, lay.H, lay.W, 4, dev)                    # NHWC4 fp16 image
+                lay.sh_geom = ops.geom(B, lay.H, lay.W, 3, 3, lay.cout, 4, 0, 1)
+                lay.sh_wp = torch.zeros(ops.packed_elems(lay.sh_geom)[0], dtype=ops.HALF, device=dev)
+                lay.sh_dst = ops.alloc_padded(B, lay.H // 2, lay.W // 2, 32, dev)          # scratch pooled output
+                lay.sh_coef = [torch.empty(lay.cout, **f32) for _ in range(4)]             # scale, shift, mean, invstd
+                lay.stem_ws = torch.empty(ops.stem_block_workspace_bytes(), dtype=torch.uint8, device=dev)
+            lay.dy = None if (lay.fused_stem or lay.stem_shadow) else ops.alloc_padded(B, lay.H, lay.W, lay.cout_p, dev)
             lay.keep, lay.keep_key = None, None
             lay.gin = None
             if lay.li > 0:
@@ -591,6 +610,8 @@ class Engine:
                 ops.pack_weights(lay.geom_f, torch.cat(parts, 1).contiguous(), None, True, False, lay.wp, None)
             if lay.wd is not None:
                 ops.pack_weights(lay.geom, w, mask, False, True, None, lay.wd)
+            if getattr(lay, "stem_shadow", False):
+                ops.pack_weights(lay.sh_geom, w, mask, True, False, lay.sh_wp, None)
 
     # ------------------------------------------------------------------ filter compaction
     def _update_compaction(self):
@@ -773,6 +794,8 @@ class Engine:
             # (written by the layout kernel itself: round 2 built the planes with torch.cat, three 3 x B x H x W fp32
             # temporaries per forward -- 0.8 GB at B=128 through the caching allocator)
             ops.nchw_to_padded_split(xs, self.bufs[tin.buf], tin.ld, tin.choff, tin.ps)
+            if training and self.layers[0].stem_shadow:
+                ops.nchw_to_padded(xs, self.layers[0].sh_img, 4, 0)
         else:
             ops.nchw_to_padded(xs, self.bufs[tin.buf], tin.ld, tin.choff)
         if self._logits is None:
@@ -827,6 +850,13 @@ class Engine:
                             momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps, cout=lay.cout,
                             planes=3 if self.precise else 1)
                 continue
+            if training and lay.stem_shadow:
+                # the fused first block on plain operands into a scratch output: fills the workspace and the coefficients
+                # its backward pass reads (no running-statistics update: the split path below owns them)
+                c = lay.sh_coef
+                ops.stem_block_fwd(B, lay.H, lay.W, lay.sh_img, lay.sh_wp, bn.weight.data, bn.bias.data, None, None, True,
+                                   c[0], c[1], c[2], c[3], lay.slope, lay.sh_dst, 32, 0, lay.stem_ws,
+                                   momentum=0.0, eps=bn.eps, cout=lay.cout, planes=1)
             if self.precise:
                 # unrounded fp32 raw output (+ batch statistics from the fp32 values), then BN + LeakyReLU
                 # (+ pool / reorg / route) written as hi | lo | hi planes
@@ -938,7 +968,7 @@ class Engine:
                 on_ready(flat, lay.p_lo, lay.p_hi)
             elif getattr(on_ready, "takes_fence", False):
                 # (the fused first block writes its whole slice on the launch stream: it needs the real fence)
-                on_ready(flat, lay.p_lo, lay.p_hi, fence if lay.fused_stem else on_side)
+                on_ready(flat, lay.p_lo, lay.p_hi, fence if (lay.fused_stem or lay.stem_shadow) else on_side)
             else:
                 with fence():
                     on_ready(flat, lay.p_lo, lay.p_hi)
@@ -991,6 +1021,19 @@ class Engine:
             pending.clear()
 
         for lay in reversed(self.layers):
+            if lay.stem_shadow:
+                flush()
+                # the first block's backward pass = the fused first block's, from the NHWC4 image, the plain-operand
+                # coefficients of its own forward call and G
+                cons = self.consumer_of[lay.out_id]
+                mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
+                c = lay.sh_coef
+                self._timed('wgrad', lay, ops.stem_block_bwd, self.B, lay.H, lay.W, lay.sh_img, lay.sh_wp,
+                            lay.bn.weight.data, c[0], c[1], c[2], c[3], lay.slope, cons.gin, cons.tin.ld,
+                            lay.out_t.choff, gmap[id(lay.conv.weight)], gmap[id(lay.bn.weight)], gmap[id(lay.bn.bias)],
+                            lay.stem_ws, mask=mask, grad_scale=D)
+                ready(lay)
+                continue
             if lay.fused_stem:
                 flush()
                 # the whole backward of the first block in one pass over the image and G (conv_stem_block.hip)
