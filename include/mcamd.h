@@ -92,6 +92,14 @@ typedef struct mcamd_conv_epilogue {
                                   the fp16 range (+-65504) on its way out.  fp16 outputs saturate instead of becoming
                                   inf; the scaled gradients of the backward pass (grad_scale x dX) are where that can
                                   happen, and the caller decides (train.py skips the step and halves grad_scale). */
+    int32_t dst_mode;          /* mode 2 only: MCAMD_DST_PLAIN (0), MCAMD_DST_POOL or MCAMD_DST_REORG -- the inference
+                                  epilogue fused with the MaxPool(2,2) / Reorg(2) that follows the block (nets.py:821,
+                                  648-667): `y` is then the padded NHWC buffer at the POOLED resolution (H/2 x W/2; reorg:
+                                  4 x cout channels from y_choff), H and W must be even, and the forward launch enumerates
+                                  its output pixels window by window.  Forward only. */
+    void* y2;                  /* dst_mode POOL, may be NULL: a second, FULL-resolution padded copy of leaky(bn(conv)) (the
+                                  route that reads the block beside its pool: conv13 of yolov2-voc.cfg) */
+    int32_t y2_ld, y2_choff;
 } mcamd_conv_epilogue;
 
 /* Rows of the BatchNorm partial-sum slab a forward launch of this geometry writes (epilogue mode 0). */

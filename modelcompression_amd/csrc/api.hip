@@ -339,6 +339,22 @@ static int fill_epilogue(IgemmArgs& a, const mcamd_conv_epilogue* e, int n_out, 
             a.scale = e->scale;
             a.shift = e->shift;
             a.slope = e->slope;
+            MCAMD_REQUIRE(e->dst_mode == MCAMD_DST_PLAIN || e->dst_mode == MCAMD_DST_POOL || e->dst_mode == MCAMD_DST_REORG,
+                          "%s: bad dst_mode %d", what, e->dst_mode);
+            if (e->dst_mode != MCAMD_DST_PLAIN) {
+                MCAMD_REQUIRE(a.H % 2 == 0 && a.W % 2 == 0 && a.ntaps > 0 && !a.stats, "%s: pooled / reorg epilogue needs even H and W", what);
+                const int span = e->dst_mode == MCAMD_DST_REORG ? 4 * n_out : n_out;
+                MCAMD_REQUIRE(e->y_choff + span <= e->y_ld, "%s: pooled output slice [%d, %d) does not fit y_ld %d", what, e->y_choff,
+                              e->y_choff + span, e->y_ld);
+                MCAMD_REQUIRE(!e->y2 || (e->dst_mode == MCAMD_DST_POOL && e->y2_ld % 8 == 0 && e->y2_choff % 8 == 0 &&
+                                         e->y2_choff + n_out <= e->y2_ld),
+                              "%s: y2 (full-resolution copy) needs dst_mode POOL and a fitting slice", what);
+                a.dst_mode = e->dst_mode;
+                a.y2 = e->y2;
+                a.y2_ld = e->y2_ld, a.y2_choff = e->y2_choff;
+            }
+        } else {
+            MCAMD_REQUIRE(e->dst_mode == 0 && !e->y2, "%s: dst_mode / y2 belong to epilogue mode 2 (MCAMD_EPI_PAD_F16)", what);
         }
     } else if (e->mode == MCAMD_EPI_RAW_F32) {
         MCAMD_REQUIRE(e->y_ld % 4 == 0 && e->y_choff % 4 == 0 && e->y_choff + n_out <= e->y_ld,
@@ -422,7 +438,8 @@ extern "C" int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const voi
     a.ktot = a.ntaps * a.cin_tap;
     fill_taps(g->ksize, g->stem, a.x_row_stride, g->x_ld, a.tap_off);
     const bool stem_direct = epi && mcamd_stem_direct_ok(g->stem, g->cout, epi->mode);
-    const bool wres = epi && mcamd_wres_ok(g->ksize, g->stem, g->cout, a.cin_tap, a.ktot, g->B, g->H, g->W, epi->mode);
+    const bool wres = epi && epi->dst_mode == MCAMD_DST_PLAIN &&
+                      mcamd_wres_ok(g->ksize, g->stem, g->cout, a.cin_tap, a.ktot, g->B, g->H, g->W, epi->mode);
     if (fill_epilogue(a, epi, g->cout, a.M, a.cin_tap, a.ktot, "conv_fwd",
                       stem_direct ? mcamd_stem_rows(a.M) : (wres ? mcamd_wres_rows(g->cout, g->B, g->H, g->W) : -1)))
         return MCAMD_EINVAL;
@@ -467,7 +484,8 @@ extern "C" int mcamd_conv_dgrad(const mcamd_conv_geom* g, const void* dy, int32_
     a.kb = kblock_of(a.cin_tap);
     a.ktot = a.ntaps * a.cin_tap;
     fill_taps(g->ksize, 0, a.x_row_stride, dy_ld, a.tap_off);
-    MCAMD_REQUIRE(epi && epi->mode != MCAMD_EPI_PAD_F16 && !epi->stats, "conv_dgrad: epilogue must be mode 0 (no stats) or 1");
+    MCAMD_REQUIRE(epi && epi->mode != MCAMD_EPI_PAD_F16 && !epi->stats && epi->dst_mode == 0 && !epi->y2,
+                  "conv_dgrad: epilogue must be mode 0 (no stats) or 1");
     if (fill_epilogue(a, epi, g->cin, a.M, a.cin_tap, a.ktot, "conv_dgrad")) return MCAMD_EINVAL;
     return mcamd_igemm_launch(a, (hipStream_t)stream);
 }

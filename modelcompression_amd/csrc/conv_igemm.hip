@@ -21,6 +21,7 @@
 // Replaces F.conv2d at reference src/pruning/weightPruning/layers.py:60-64 and its autograd
 // input gradient.
 #include "kernels.h"
+#include "epi_pool.h"
 #include <stdlib.h>
 
 
@@ -99,10 +100,15 @@ void igemm_kernel(IgemmArgs a) {
             int logical = phys ^ swz<CPR>(row);
             int m = mt * BM + row;
             if (m > a.M - 1) m = a.M - 1;  // tail rows re-read the last pixel; their results are masked
-            int b = m / a.HW;
-            int rem = m - b * a.HW;
-            int h = rem / a.W;
-            int w = rem - h * a.W;
+            int b, h, w;
+            if (EPI == MCAMD_EPI_PAD_F16 && a.dst_mode != 0) {   // pooled order: four consecutive rows = one 2x2 window
+                pooled_pixel(a, m, b, h, w);
+            } else {
+                b = m / a.HW;
+                const int rem = m - b * a.HW;
+                h = rem / a.W;
+                w = rem - h * a.W;
+            }
             abase[it] = (long long)b * a.x_img_stride + (long long)h * a.x_row_stride + (long long)w * a.x_ld +
                         a.x_off + logical * 8;
         }
@@ -277,6 +283,10 @@ void igemm_kernel(IgemmArgs a) {
             __syncthreads();
             constexpr int CH = BN / 8;  // 16-byte chunks per output row
             half_t* y = (half_t*)a.y;
+            if (EPI == MCAMD_EPI_PAD_F16 && a.dst_mode != 0) {
+                store_pad_pooled<BM, BN, NT>(a, ct, mt, nt, tid);
+                continue;
+            }
             for (int slot = tid; slot < BM * CH; slot += NT) {
                 int row = slot / CH, ch = slot - row * CH;
                 int m = mt * BM + row;

@@ -37,6 +37,7 @@
 // sums and the epilogues are those of conv_igemm.hip.  Replaces F.conv2d at reference
 // src/pruning/weightPruning/layers.py:60-64 and its autograd input gradient.
 #include "kernels.h"
+#include "epi_pool.h"
 #include <stdlib.h>
 
 namespace {
@@ -146,10 +147,15 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
             const int row = (slot / CPR) % BM, phys = slot % CPR;   // (slots beyond the tile, BM = 192: never issued)
             int m = mt * BM + row;
             if (m > a.M - 1) m = a.M - 1;   // tail rows re-read the last pixel; their results are masked
-            const int b = m / a.HW;
-            const int rem = m - b * a.HW;
-            const int h = rem / a.W;
-            const int w = rem - h * a.W;
+            int b, h, w;
+            if (EPI == MCAMD_EPI_PAD_F16 && a.dst_mode != 0) {   // pooled order: four consecutive rows = one 2x2 window
+                pooled_pixel(a, m, b, h, w);
+            } else {
+                b = m / a.HW;
+                const int rem = m - b * a.HW;
+                h = rem / a.W;
+                w = rem - h * a.W;
+            }
             abase[it] = (long long)b * a.x_img_stride + (long long)h * a.x_row_stride + (long long)w * a.x_ld + a.x_off +
                         (phys ^ SH::swz4(row)) * 8;
         }
@@ -356,6 +362,10 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
             __syncthreads();
             constexpr int CH = BN / 8;
             half_t* y = (half_t*)a.y;
+            if (EPI == MCAMD_EPI_PAD_F16 && a.dst_mode != 0) {
+                store_pad_pooled<BM, BN, NT>(a, ct, mt, nt, tid);
+                continue;
+            }
             for (int slot = tid; slot < BM * CH; slot += NT) {
                 const int row = slot / CH, ch = slot - row * CH;
                 const int m = mt * BM + row;

@@ -29,6 +29,11 @@ struct IgemmArgs {
     int num_ntiles;
     int xcd_order;
     int* overflow;   // optional: set to 1 when an fp16 output was clamped to +-65504
+    // inference epilogue fused with MaxPool(2,2) / Reorg(2) (MCAMD_EPI_PAD_F16 only, epi_pool.h): dst_mode != 0 enumerates
+    // the M tile in pooled order and `y` is at the pooled resolution; y2 = optional full-resolution copy (POOL)
+    int dst_mode;
+    void* y2;
+    int y2_ld, y2_choff;
 };
 
 struct StemArgs {        // conv_stem.hip: forward of the 3-channel first layer

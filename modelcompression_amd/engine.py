@@ -495,13 +495,14 @@ class Engine:
         for lay in self.layers:
             w = lay.conv.weight
             m = lay.conv.mask if lay.conv.mask_flag else None
-            sig.append((w.data_ptr(), w._version, None if m is None else (m.data_ptr(), m._version)))
+            bnv = None
             if lay.fold is not None and not getattr(self, "_training", True):
                 # eval: the folded constants beta - running_mean * gamma / sqrt(running_var + eps) are baked into the
                 # augmented weights -- an in-place change of the producer's BatchNorm tensors (dp.sync_buffers,
                 # running_mean.copy_, load_state_dict) must trigger a re-pack
                 bn = lay.fold.bn
-                sig.append(tuple(t._version for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)))
+                bnv = tuple(t._version for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+            sig.append((w.data_ptr(), w._version, None if m is None else (m.data_ptr(), m._version), bnv))
         return tuple(sig)
 
     def pack(self, force=False, training=True):
@@ -872,15 +873,19 @@ class Engine:
                                t2.ld if t2 is not None else 0, t2.choff if t2 is not None else 0, border=lay.border,
                                planes=3, dst_plane=t.ps, dst2_plane=t2.ps if t2 is not None else 0)
                 continue
-            if (not training and self.fuse_eval and lay.mode == L.DST_PLAIN and lay.perm is None and lay.border is None
-                    and lay.out2_t is None):
-                # inference: BN (running statistics) + LeakyReLU in the conv epilogue, written straight into the
-                # consumer's padded buffer -- the raw output is never stored (one fp16 rounding per layer, no second pass)
+            if (not training and self.fuse_eval and lay.perm is None and lay.border is None
+                    and (lay.out2_t is None or lay.mode == L.DST_POOL)
+                    and (lay.mode == L.DST_PLAIN or (lay.H % 2 == 0 and lay.W % 2 == 0))):
+                # inference: BN (running statistics) + LeakyReLU -- and the MaxPool / Reorg that follows the block -- in the
+                # conv epilogue, written straight into the consumer's padded buffer: the raw output is never stored (one
+                # fp16 rounding per layer, no second pass)
                 ops.bn_coeffs(None, lay.cout, lay.M, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, False,
                               lay.scale, lay.shift, lay.mean, lay.invstd, eps=bn.eps)
-                t = lay.out_t
+                t, t2 = lay.out_t, lay.out2_t
                 self._timed('fwd', lay, ops.conv_fwd_padded, lay.geom_act, xin, lay.wp, self.bufs[t.buf], t.ld, t.choff,
-                            lay.scale, lay.shift, lay.slope)
+                            lay.scale, lay.shift, lay.slope, dst_mode=lay.mode,
+                            y2=self.bufs[t2.buf] if t2 is not None else None,
+                            y2_ld=t2.ld if t2 is not None else 0, y2_choff=t2.choff if t2 is not None else 0)
                 continue
             self._timed('fwd', lay, ops.conv_fwd_raw, lay.geom_act, xin, lay.wp, lay.y, lay.cout, 0, lay.stats if training else None)
             ops.bn_coeffs(lay.stats if training else None, lay.cout, lay.M, bn.weight.data, bn.bias.data,

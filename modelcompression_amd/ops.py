@@ -119,7 +119,7 @@ def stats_rows(g, mode=L.EPI_RAW_F16):
 
 
 def _epi(mode, y, y_ld=0, y_choff=0, bias=None, stats=None, stats_rows_=0, stats_ld=0, scale=None, shift=None,
-         slope=1.0, overflow=None):
+         slope=1.0, overflow=None, dst_mode=0, y2=None, y2_ld=0, y2_choff=0):
     e = ConvEpilogue()
     e.mode, e.y_ld, e.y_choff = mode, y_ld, y_choff
     e.y = y.data_ptr()
@@ -130,6 +130,9 @@ def _epi(mode, y, y_ld=0, y_choff=0, bias=None, stats=None, stats_rows_=0, stats
     e.shift = shift.data_ptr() if shift is not None else None
     e.slope = slope
     e.overflow = overflow.data_ptr() if overflow is not None else None
+    e.dst_mode = dst_mode
+    e.y2 = y2.data_ptr() if y2 is not None else None
+    e.y2_ld, e.y2_choff = y2_ld, y2_choff
     return e
 
 
@@ -155,8 +158,11 @@ def conv_fwd_nchw(g, x, wp, y, bias=None):
     check(L.lib().mcamd_conv_fwd(C.byref(g), ptr(x), ptr(wp), C.byref(e), stream_ptr()), "mcamd_conv_fwd")
 
 
-def conv_fwd_padded(g, x, wp, y, y_ld, y_choff=0, scale=None, shift=None, slope=1.0):
-    e = _epi(L.EPI_PAD_F16, y, y_ld, y_choff, scale=scale, shift=shift, slope=slope)
+def conv_fwd_padded(g, x, wp, y, y_ld, y_choff=0, scale=None, shift=None, slope=1.0, dst_mode=0, y2=None, y2_ld=0, y2_choff=0):
+    """Inference: leaky(conv * scale + shift) straight into a padded NHWC buffer.  `dst_mode` = L.DST_POOL / L.DST_REORG fuses
+    the MaxPool(2,2) / Reorg(2) that follows the block (y is then at the pooled resolution); `y2`: optional full-resolution copy."""
+    e = _epi(L.EPI_PAD_F16, y, y_ld, y_choff, scale=scale, shift=shift, slope=slope, dst_mode=dst_mode, y2=y2, y2_ld=y2_ld,
+             y2_choff=y2_choff)
     check(L.lib().mcamd_conv_fwd(C.byref(g), ptr(x), ptr(wp), C.byref(e), stream_ptr()), "mcamd_conv_fwd")
 
 

@@ -677,3 +677,50 @@ def test_wres_kernel_vs_igemm(dev, setenv, B, H, W, cin, cout):
     refp = F.leaky_relu(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), 0.1)
     assert rel_l2(got, refp) < TOL
     assert halo_is_zero(dst, B, H, W, 320)
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,mode,dual", [
+    (2, 16, 24, 64, 64, "pool", False),       # igemm_kernel 128x64
+    (3, 26, 26, 128, 256, "pool", True),      # igemm / ping-pong tile, pooled + full-resolution copy (conv13's route)
+    (4, 52, 52, 128, 256, "pool", False),     # ping-pong 256-wide tiles (K = 1152)
+    (2, 26, 26, 512, 64, "reorg", False),     # conv21: 1x1, reorg(2) into a 256-channel slice
+    (1, 6, 10, 32, 24, "pool", False),        # ragged tile, 24 channels
+])
+def test_conv_fwd_padded_pool_reorg_epilogue(dev, B, H, W, cin, cout, mode, dual):
+    """Inference epilogue fused with the MaxPool(2,2) / Reorg(2) that follows the block (include/mcamd.h,
+    mcamd_conv_epilogue.dst_mode): leaky(conv * scale + shift) pooled / reorg'ed straight into the consumer's padded buffer,
+    optionally with a full-resolution copy -- reference nets.py:802-821 (conv, BatchNorm in eval mode, LeakyReLU, MaxPool) and
+    nets.py:648-667 (Reorg)."""
+    from modelcompression_amd import _lib as L
+    from oracle import darknet_ref as O
+    k = 1 if mode == "reorg" else 3
+    x, w = _rand_case(B, H, W, cin, cout, k, seed=31)
+    scale, shift = torch.rand(cout) + 0.5, torch.randn(cout) * 0.2
+    xb, ld = to_padded(x.to(dev))
+    g = ops.geom(B, H, W, k, cin, cout, ld)
+    wp, _ = ops.pack_weights(g, w.to(dev).contiguous())
+    act = F.leaky_relu(F.conv2d(q16(x), q16(w), None, 1, (k - 1) // 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), 0.1)
+    Ho, Wo = H // 2, W // 2
+    if mode == "pool":
+        cdst, off = cout, 8
+        ref = F.max_pool2d(act, 2, 2)
+    else:
+        cdst, off = 4 * cout, 64
+        ref = O.reorg(act, 2)
+    dld = ops.round_up(off + cdst, 32)
+    dst = ops.alloc_padded(B, Ho, Wo, dld, dev)
+    dst2 = ops.alloc_padded(B, H, W, ops.round_up(cout + 32, 32), dev) if dual else None
+    ops.conv_fwd_padded(g, xb, wp, dst, dld, off, scale.to(dev), shift.to(dev), 0.1,
+                        dst_mode=L.DST_POOL if mode == "pool" else L.DST_REORG, y2=dst2,
+                        y2_ld=ops.round_up(cout + 32, 32) if dual else 0, y2_choff=32 if dual else 0)
+    got = padded_to_nchw(dst, B, Ho, Wo, dld, cdst, off)
+    assert rel_l2(got, ref) < TOL
+    assert halo_is_zero(dst, B, Ho, Wo, dld)
+    v = ops.padded_view(dst, B, Ho, Wo, dld)
+    assert float(v[..., :off].abs().sum()) == 0 and float(v[..., off + cdst:].abs().sum()) == 0
+    if dual:
+        got2 = padded_to_nchw(dst2, B, H, W, ops.round_up(cout + 32, 32), cout, 32)
+        assert rel_l2(got2, act) < TOL
+        assert halo_is_zero(dst2, B, H, W, ops.round_up(cout + 32, 32))
+        # the pooled output is exactly the maximum of the stored full-resolution values
+        assert torch.equal(got, F.max_pool2d(got2, 2, 2))
