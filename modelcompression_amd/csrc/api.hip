@@ -567,7 +567,9 @@ extern "C" int mcamd_conv_wgrad(const mcamd_conv_geom* g, const void* x, const v
     if (rc) return rc;
     if (dbias) {
         long long rows = (long long)g->B * (g->H + 2) * (g->W + 2);
-        rc = mcamd_colsum_launch((const half_t*)dy, rows, dy_ld, dy_choff, g->cout, 1.0f / grad_scale, dbias, st);
+        // (the split-K slabs are consumed by the finish pass enqueued above: the workspace is free again, in stream order)
+        rc = mcamd_colsum_launch((const half_t*)dy, rows, dy_ld, dy_choff, g->cout, 1.0f / grad_scale, dbias, st, workspace,
+                                 workspace_bytes);
     }
     return rc;
 }

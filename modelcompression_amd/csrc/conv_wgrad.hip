@@ -27,7 +27,27 @@ struct PixState {
 // (KP pixels x TNc each, shifted by the tap), so dY -- the big operand of the early layers -- is
 // read TAPS times less often.  Wave w owns filter block i = w % NI (NI = TMo/32) and every
 // WPI-th (tap, cin-block) task: one A fragment per k16 step feeds all its MFMAs.
-template <int TMo, int TNc, int TAPS, int KP>
+__device__ __forceinline__ void wait_vm_dyn(int n) {
+    // n is wave-uniform (scalar branches); s_waitcnt takes an immediate
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // more than asked for is always safe
+    }
+}
+
+template <int TMo, int TNc, int TAPS, int KP, int NS>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     constexpr int NT = 256;
     constexpr int NI = TMo / 32, WPI = 4 / NI, NJ = TNc / 32;
@@ -152,13 +172,31 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         }
     };
 
-    if (nsteps > 0) stage(0);
+    // NS-deep ring (NS = 3 where three stages fit next to two more workgroups of the CU): the DMA of step st + NS - 1 is
+    // issued right after the barrier of step st, and the wait in front of the barrier counts this wave's DMA instructions
+    // of the younger stages (round 2: two stages and `vmcnt(0)` -- the 1x1 weight gradients ran at 200-240 TFLOP/s)
+    int cnt = 0;               // DMA instructions this wave issues per stage (wave-uniform)
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) cnt += (it * NT + wave * 64 < A_SLOTS) ? 1 : 0;
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) cnt += (it * NT + wave * 64 < B_SLOTS) ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < NS - 1; ++k)
+        if (k < nsteps) stage(k);
+    int slot = 0;
     for (int st = 0; st < nsteps; ++st) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int ahead = nsteps - 1 - st;
+        if (ahead > NS - 2) ahead = NS - 2;
+        wait_vm_dyn(ahead * cnt);
         __syncthreads();
-        if (st + 1 < nsteps) stage((st + 1) & 1);
-        const unsigned sa = smem_addr + (st & 1) * STAGE_BYTES;
+        if (st + NS - 1 < nsteps) {
+            int ns_ = slot + NS - 1;
+            if (ns_ >= NS) ns_ -= NS;
+            stage(ns_);
+        }
+        const unsigned sa = smem_addr + slot * STAGE_BYTES;
         const unsigned sb = sa + A_SLOTS * 16;
+        slot = slot + 1 == NS ? 0 : slot + 1;
 #pragma unroll
         for (int s = 0; s < KP / 16; ++s) {
             if constexpr (SQ) {
@@ -343,25 +381,6 @@ __global__ __launch_bounds__(256, 2) void wgrad9_kernel(Wgrad9Args a) {
 // drains the ring before the first read of a step and a lone workgroup would never overlap DMA with MFMA).
 // Fragments are double-buffered across the k16 sub-steps: the reads of sub-step s + 1 are issued before the MFMAs
 // of sub-step s.
-__device__ __forceinline__ void wait_vm_dyn(int n) {
-    // n is wave-uniform (scalar branches); s_waitcnt takes an immediate
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // more than asked for is always safe
-    }
-}
 
 // lane offset (bytes from the tile start) of the first of a fragment's two transposing reads; the second one is 4
 // rows further (same swizzle for 128- and 256-byte rows), sub-step s is 16 rows further (same swizzle again), so both
@@ -884,9 +903,12 @@ WgradPlan mcamd_wgrad_plan(long long M, int cout, int cin_tap, int ntaps) {
 
 template <int TMo, int TNc, int TAPS, int KP>
 static void launch_w(const WgradArgs& a, int grid, hipStream_t st) {
-    size_t lds = 2 * (size_t)(KP * (TMo / 8) + TAPS * KP * (TNc / 8)) * 16;
-    if (lds > 64 * 1024) MCAMD_LDS_OPT_IN((wgrad_kernel<TMo, TNc, TAPS, KP>), lds);   // lds is a per-instance constant
-    hipLaunchKernelGGL((wgrad_kernel<TMo, TNc, TAPS, KP>), dim3(grid), dim3(256), lds, st, a);
+    constexpr size_t stage = (size_t)(KP * (TMo / 8) + TAPS * KP * (TNc / 8)) * 16;
+    // three stages where three workgroups of them still fit a CU's 160 KB (the 1x1 layers: 16-24 KB stages)
+    constexpr int NS = (3 * stage * 3 <= 156 * 1024) ? 3 : 2;
+    constexpr size_t lds = NS * stage;
+    if (lds > 64 * 1024) MCAMD_LDS_OPT_IN((wgrad_kernel<TMo, TNc, TAPS, KP, NS>), lds);   // lds is a per-instance constant
+    hipLaunchKernelGGL((wgrad_kernel<TMo, TNc, TAPS, KP, NS>), dim3(grid), dim3(256), lds, st, a);
 }
 
 int mcamd_wgrad_launch(WgradArgs& a, const WgradPlan& p, hipStream_t st) {
@@ -968,9 +990,69 @@ int mcamd_wgrad_finish_launch(const float* slab, const WgradPlan& p, int ktot, i
     return MCAMD_OK;
 }
 
+// Two-pass column sum with whole-line reads: 128 blocks sum 16 rows x 128 channels per step (16-byte loads) into one
+// partial row each, one block adds the partials in a fixed order.  (colsum_kernel above, one block per CHANNEL reading
+// 2-byte elements at a row stride, took 30 us for conv23's 14 400 x 125 dY: the slowest "tiny" launch of the step.)
+__global__ __launch_bounds__(256) void colsum_part_kernel(const half_t* dy, long long rows, int ld, int choff, int C, float* part) {
+    __shared__ float red[16][129];
+    const int cg = threadIdx.x & 15, rsub = threadIdx.x >> 4;
+    const int Cp = (C + 7) & ~7;
+    for (int c0 = 0; c0 < Cp; c0 += 128) {
+        float s[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = 0.f;
+        const int c = c0 + cg * 8;
+        if (c < Cp)
+            for (long long r = (long long)blockIdx.x * 16 + rsub; r < rows; r += (long long)gridDim.x * 16) {
+                const h8_t v = *(const h8_t*)(dy + r * ld + choff + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[rsub][cg * 8 + e] = s[e];
+        __syncthreads();
+        if (threadIdx.x < 128 && c0 + threadIdx.x < Cp) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v += red[k][threadIdx.x];
+            part[(long long)blockIdx.x * Cp + c0 + threadIdx.x] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* part, int nblk, int C, float inv_scale, float* out) {
+    // thread = (channel n of a pass of 128, partial group kg of 8): 16 partials each, then the 8 group sums in order
+    __shared__ float red[8][128];
+    const int Cp = (C + 7) & ~7;
+    const int nl = threadIdx.x & 127, kg = threadIdx.x >> 7;
+    for (int c0 = 0; c0 < C; c0 += 128) {
+        const int n = c0 + nl;
+        float v = 0.f;
+        if (n < C)
+            for (int k = kg; k < nblk; k += 8) v += part[(long long)k * Cp + n];
+        __syncthreads();
+        red[kg][nl] = v;
+        __syncthreads();
+        if (kg == 0 && n < C) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) t += red[g][nl];
+            out[n] = t * inv_scale;
+        }
+    }
+}
+
 int mcamd_colsum_launch(const half_t* dy, long long rows, int ld, int choff, int C, float inv_scale, float* out,
-                        hipStream_t st) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(C), dim3(256), 0, st, dy, rows, ld, choff, C, inv_scale, out);
+                        hipStream_t st, void* scratch, size_t scratch_bytes) {
+    constexpr int NBLK = 128;
+    const size_t need = (size_t)NBLK * ((C + 7) & ~7) * sizeof(float);
+    if (scratch && scratch_bytes >= need && choff % 8 == 0 && ld % 8 == 0) {
+        hipLaunchKernelGGL(colsum_part_kernel, dim3(NBLK), dim3(256), 0, st, dy, rows, ld, choff, C, (float*)scratch);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(1024), 0, st, (const float*)scratch, NBLK, C, inv_scale, out);
+    } else {
+        hipLaunchKernelGGL(colsum_kernel, dim3(C), dim3(256), 0, st, dy, rows, ld, choff, C, inv_scale, out);
+    }
     MCAMD_LAUNCH_CHECK("colsum");
     return MCAMD_OK;
 }

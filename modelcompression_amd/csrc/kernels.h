@@ -90,7 +90,7 @@ int mcamd_wgrad_finish_launch(const float* slab, const WgradPlan& p, int ktot, i
                               int ksize, const float* mask, float inv_scale, float* dw, const int* rmap, const int* cmap,
                               hipStream_t st);
 int mcamd_colsum_launch(const half_t* dy, long long rows, int ld, int choff, int C, float inv_scale, float* out,
-                        hipStream_t st);
+                        hipStream_t st, void* scratch, size_t scratch_bytes);   // scratch: reusable once the finish pass is enqueued
 
 bool mcamd_win3x3_ok(const IgemmArgs& a);                             // conv_win.hip
 bool mcamd_win3x3_shape(long long M, int n, int cin_tap, int ktot, int W);

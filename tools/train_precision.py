@@ -62,6 +62,22 @@ for prec in ("fp16", "mixed", "fp16x3"):
         step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / K * 1e3
+    if os.environ.get("LAYERS") == prec:
+        eng2 = [e_ for e_ in model._engines.values() if e_.precision == prec][0]
+        eng2.events = []
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        ev, eng2.events = eng2.events, None
+        per = {}
+        for tag, lay, e0, e1 in ev:
+            per.setdefault((lay.li + 1, tag), []).append(e0.elapsed_time(e1))
+        tot = {}
+        for (li, tag), v in sorted(per.items()):
+            ms_ = sum(v) / len(v)
+            tot[tag] = tot.get(tag, 0) + ms_
+            print("   conv%-2d %-5s %.3f ms" % (li, tag, ms_))
+        print("   totals", {k: round(v, 3) for k, v in tot.items()})
     print("%-7s train logits rel-L2 %.2e (worst image %.2e) at B=%d | %.2f ms/step = %.0f img/s at B=%d | plain blocks %s" % (
         prec, e, worst, BP, ms, BT / ms * 1e3, BT, plain), flush=True)
     model._engines = {}
