@@ -55,9 +55,9 @@ t2 = time.perf_counter()
 es = []
 for _ in range(20):
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    q0 = time.perf_counter()
     step()
-    es.append((time.perf_counter() - t0) * 1e3)
+    es.append((time.perf_counter() - q0) * 1e3)
 torch.cuda.synchronize()
 es.sort()
 print("%s B=%d: enqueue of one step into an empty queue: median %.2f ms, min %.2f ms" % (wl, B, es[len(es) // 2], es[0]))
