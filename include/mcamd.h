@@ -374,6 +374,27 @@ int mcamd_nchw_f32_to_padded_nhwc_f16_split(const float* src, int32_t B, int32_t
                                             void* dst, int32_t dst_ld, int32_t dst_choff, int32_t plane, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Region loss of the training step (reference src/nets.py:282-635: build_targets + RegionLoss.forward, called at
+ * train.py:224): loss AND d(loss)/d(output) in one pass over the logits; the targets are built per image in LDS.
+ *   output : fp32 [B][num_anchors * (5 + num_classes)][H][W] -- what Darknet.forward returns (nets.py:720-774)
+ *   target : fp32 [B][max_boxes * 5] rows of (class, x, y, w, h), normalised to [0, 1]; a row list ends at the first x == 0
+ *   anchors: num_anchors (w, h) pairs in grid units (the [region] block of the cfg)
+ *   loss   : device fp32 scalar = the value RegionLoss.forward returns (sum of the six terms / B)
+ *   grad   : device fp32, shaped like output: d(loss)/d(output)
+ *   counts : optional device int32[2] (nGT, nCorrect; the reference prints them), ADDED to -- zero them first
+ * The reference's arithmetic quirks are kept (modelcompression_amd/region_loss.py lists them).  Deterministic.
+ * ------------------------------------------------------------------------- */
+typedef struct mcamd_region_desc {
+    const float* output; const float* target;
+    int32_t B, H, W, num_anchors, num_classes, max_boxes;   /* max_boxes must be 50 (nets.py:312) */
+    float anchors[16];
+    float coord_scale, noobject_scale, object_scale, class_scale, thresh;
+} mcamd_region_desc;
+size_t mcamd_region_loss_workspace_bytes(int32_t B);
+int mcamd_region_loss(const mcamd_region_desc* d, float* loss, float* grad, int32_t* counts, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Launch plans: a whole forward or backward pass as ONE library call.
  * The reference executes Darknet.forward as one Python call per torch module (src/nets.py:720-774) and autograd
  * replays them; here the caller walks its layer list ONCE between mcamd_plan_begin and mcamd_plan_end: every

@@ -81,6 +81,14 @@ class StemBlockDesc(C.Structure):
                 ("dw", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("cout", C.c_int32), ("planes", C.c_int32)]
 
 
+class RegionDesc(C.Structure):
+    _fields_ = [("output", C.c_void_p), ("target", C.c_void_p),
+                ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("num_anchors", C.c_int32), ("num_classes", C.c_int32),
+                ("max_boxes", C.c_int32), ("anchors", C.c_float * 16),
+                ("coord_scale", C.c_float), ("noobject_scale", C.c_float), ("object_scale", C.c_float),
+                ("class_scale", C.c_float), ("thresh", C.c_float)]
+
+
 class FoldJob(C.Structure):
     _fields_ = [("d", FoldDesc), ("waug", C.c_void_p), ("first_block", C.c_int64)]
 
@@ -119,6 +127,8 @@ SIGNATURES = {
     "mcamd_stem_block_bwd": (C.c_int, [C.POINTER(StemBlockDesc), _P, _SZ, _P]),
     "mcamd_nchw_f32_to_padded_nhwc_f16": (C.c_int, [_P, _I32, _I32, _I32, _I32, _F, _P, _I32, _I32, _P, _P]),
     "mcamd_nchw_f32_to_padded_nhwc_f16_split": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _P]),
+    "mcamd_region_loss_workspace_bytes": (_SZ, [_I32]),
+    "mcamd_region_loss": (C.c_int, [C.POINTER(RegionDesc), _P, _P, _P, _P, _SZ, _P]),
     "mcamd_plan_begin": (C.c_int, [C.POINTER(_P), _I32]),
     "mcamd_plan_mark": (_I32, []),
     "mcamd_plan_end": (_P, []),

@@ -31,6 +31,7 @@ SOURCES = {
     "bn_act.hip": [],
     "fold.hip": [],
     "plan.hip": [],
+    "region_loss.hip": [],
     "prune.hip": ["-ffp-contract=off"],   # pinned fp32 arithmetic: no FMA contraction
 }
 

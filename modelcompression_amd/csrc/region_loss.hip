@@ -1,0 +1,197 @@
+// YOLOv2 region loss (reference src/nets.py:282-635: build_targets + RegionLoss.forward) as ONE pass over the logits:
+// loss and d(loss)/d(logits) together.
+//
+// The reference builds its targets with nested Python loops on the CPU; round 2 restated them as ~60 batched torch
+// operations on the device (region_loss.py: no host synchronisation, but 1.7 ms of small launches per B=64 step, forward
+// and autograd backward, next to a 9.4 ms conv step).  The loss is a closed form of the logits once the targets are known,
+// and the targets depend on the logits only through detached quantities, so the gradient is analytic:
+//   x = sig(o0), y = sig(o1), w = exp(o2), h = exp(o3), conf = sig(o4), p = softmax(o5..)
+//   L = 1/nB * sum_n [ cs*cm/2 ((x-tx)^2 + (y-ty)^2 + (w-tw)^2 + (h-th)^2) + confmask/2 (conf-tconf)^2 + cls_s*clsm*CE(p, tcls) ]
+//   dL/do0 = cs*cm (x-tx) x(1-x) / nB, dL/do2 = cs*cm (w-tw) w / nB, dL/do4 = confmask (conf-tconf) conf(1-conf) / nB,
+//   dL/do(5+c) = cls_s*clsm (p_c - [c == tcls]) / nB
+// with the reference's quirks kept (region_loss.py header): boxes for the IoU tests use exp(w) * anchor (double exp),
+// tw = gw / anchor, conf_mask enters as its square root on both sides (= conf_mask itself on the squared error),
+// ground-truth rows end at the first x == 0, the later of two boxes in one cell / anchor wins.
+// One workgroup per image: ground-truth rows in LDS, every thread walks predictions n = (anchor, row, column).
+// Deterministic: per-image partial losses, summed in order by a second one-block launch.
+#include "common.h"
+
+namespace {
+constexpr int MAXT = 50, NTHR = 256;
+
+__device__ __forceinline__ float iou_cwh(float x1, float y1, float w1, float h1, float x2, float y2, float w2, float h2) {
+    // nets2_utils.py:100-131 bbox_ious(x1y1x2y2=False)
+    const float mx = fminf(x1 - w1 / 2.0f, x2 - w2 / 2.0f), Mx = fmaxf(x1 + w1 / 2.0f, x2 + w2 / 2.0f);
+    const float my = fminf(y1 - h1 / 2.0f, y2 - h2 / 2.0f), My = fmaxf(y1 + h1 / 2.0f, y2 + h2 / 2.0f);
+    const float cw = w1 + w2 - (Mx - mx), ch = h1 + h2 - (My - my);
+    float carea = cw * ch;
+    if (cw <= 0.f || ch <= 0.f) carea = 0.f;
+    const float uarea = w1 * h1 + w2 * h2 - carea;
+    return carea / uarea;
+}
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+}  // namespace
+
+struct RegionArgs {
+    const float* out;     // [B][A*(5+C)][H][W]
+    const float* target;  // [B][MAXT*5]
+    float* grad;          // [B][A*(5+C)][H][W]
+    float* partial;       // [B] per-image loss (already / nB)
+    int* counts;          // [2] nGT, nCorrect (may be NULL; zeroed by the caller)
+    int B, A, C, H, W;
+    float aw[8], ah[8];
+    float coord_scale, noobject_scale, object_scale, class_scale, thresh;
+};
+
+__global__ __launch_bounds__(NTHR) void region_loss_kernel(RegionArgs a) {
+    __shared__ float gx[MAXT], gy[MAXT], gw[MAXT], gh[MAXT], gcls[MAXT];
+    __shared__ int gcell[MAXT], gbest[MAXT], gwriter[MAXT];
+    __shared__ int nvalid;
+    __shared__ float red[NTHR];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int HW = a.H * a.W, N = a.A * HW, K = 5 + a.C;
+    const float* tg = a.target + (long long)b * MAXT * 5;
+    if (tid == 0) {
+        int t = 0;
+        while (t < MAXT && tg[t * 5 + 1] != 0.f) ++t;      // rows end at the first x == 0 (nets.py:324, 374)
+        nvalid = t;
+    }
+    __syncthreads();
+    const int T = nvalid;
+    if (tid < T) {
+        const float x = tg[tid * 5 + 1] * a.W, y = tg[tid * 5 + 2] * a.H, w = tg[tid * 5 + 3] * a.W, h = tg[tid * 5 + 4] * a.H;
+        gx[tid] = x, gy[tid] = y, gw[tid] = w, gh[tid] = h, gcls[tid] = tg[tid * 5];
+        // best anchor by shape IoU: first maximum of the strict '>' loop; none above 0 -> best_n = -1 = the last anchor
+        int best = a.A - 1;
+        float bi = 0.f;
+        for (int n = 0; n < a.A; ++n) {
+            float v = iou_cwh(0.f, 0.f, a.aw[n], a.ah[n], 0.f, 0.f, w, h);
+            if (!(v == v)) v = 0.f;
+            if (v > bi) bi = v, best = n;
+        }
+        gbest[tid] = best;
+        int gi = (int)x, gj = (int)y;
+        gi = gi < 0 ? 0 : (gi > a.W - 1 ? a.W - 1 : gi);
+        gj = gj < 0 ? 0 : (gj > a.H - 1 ? a.H - 1 : gj);
+        gcell[tid] = (best * a.H + gj) * a.W + gi;
+    }
+    __syncthreads();
+    if (tid < T) {
+        int wr = 1;
+        for (int t2 = tid + 1; t2 < T; ++t2)
+            if (gcell[t2] == gcell[tid]) wr = 0;           // a later box in the same cell / anchor overwrites this one
+        gwriter[tid] = wr;
+    }
+    __syncthreads();
+
+    const float inv_nb = 1.0f / (float)a.B;
+    float lsum = 0.f;
+    int correct = 0;
+    for (int n = tid; n < N; n += NTHR) {
+        const int an = n / HW, r = n - an * HW, j = r / a.W, i = r - j * a.W;
+        const long long base = ((long long)b * a.A * K + (long long)an * K) * HW + r;
+        const float o0 = a.out[base], o1 = a.out[base + HW], o2 = a.out[base + 2 * HW], o3 = a.out[base + 3 * HW],
+                    o4 = a.out[base + 4 * HW];
+        const float x = sigmoidf_(o0), y = sigmoidf_(o1), w = expf(o2), h = expf(o3), conf = sigmoidf_(o4);
+        // predicted box in grid units, with the reference's second exponential (nets.py:511-512, 546-547)
+        const float px = x + (float)i, py = y + (float)j, pw = expf(w) * a.aw[an], ph = expf(h) * a.ah[an];
+        float best = 0.f;
+        int wt = -1;
+        for (int t = 0; t < T; ++t) {
+            const float v = iou_cwh(px, py, pw, ph, gx[t], gy[t], gw[t], gh[t]);
+            best = fmaxf(best, v);                           // (fmaxf drops a NaN; .amax(2).clamp_min(0) on the torch side)
+            if (gwriter[t] && gcell[t] == n) wt = t;
+        }
+        float conf_mask = best > a.thresh ? 0.f : a.noobject_scale;
+        float cm = 0.f, tx = 0.f, ty = 0.f, tw = 0.f, th = 0.f, tconf = 0.f;
+        int tcls = 0;
+        if (wt >= 0) {
+            cm = 1.f;
+            conf_mask = a.object_scale;
+            tx = gx[wt] - (float)(int)gx[wt];
+            ty = gy[wt] - (float)(int)gy[wt];
+            tw = gw[wt] / a.aw[gbest[wt]];
+            th = gh[wt] / a.ah[gbest[wt]];
+            tconf = iou_cwh(gx[wt], gy[wt], gw[wt], gh[wt], px, py, pw, ph);
+            tcls = (int)gcls[wt];
+        }
+        const float dx = x - tx, dy = y - ty, dw = w - tw, dh = h - th, dc = conf - tconf;
+        float l = a.coord_scale * cm * 0.5f * (dx * dx + dy * dy + dw * dw + dh * dh) + conf_mask * 0.5f * dc * dc;
+        a.grad[base] = a.coord_scale * cm * dx * x * (1.f - x) * inv_nb;
+        a.grad[base + HW] = a.coord_scale * cm * dy * y * (1.f - y) * inv_nb;
+        a.grad[base + 2 * HW] = a.coord_scale * cm * dw * w * inv_nb;
+        a.grad[base + 3 * HW] = a.coord_scale * cm * dh * h * inv_nb;
+        a.grad[base + 4 * HW] = conf_mask * dc * conf * (1.f - conf) * inv_nb;
+        if (cm != 0.f) {
+            float mx = -3.4e38f;
+            for (int c = 0; c < a.C; ++c) mx = fmaxf(mx, a.out[base + (5 + c) * HW]);
+            float se = 0.f;
+            for (int c = 0; c < a.C; ++c) se += expf(a.out[base + (5 + c) * HW] - mx);
+            const float lse = mx + logf(se);
+            for (int c = 0; c < a.C; ++c) {
+                const float oc = a.out[base + (5 + c) * HW];
+                a.grad[base + (5 + c) * HW] = a.class_scale * (expf(oc - lse) - (c == tcls ? 1.f : 0.f)) * inv_nb;
+            }
+            l += a.class_scale * (lse - a.out[base + (5 + tcls) * HW]);
+        } else {
+            for (int c = 0; c < a.C; ++c) a.grad[base + (5 + c) * HW] = 0.f;
+        }
+        lsum += l;
+    }
+    // nGT / nCorrect: the reference counts every valid box whose IoU with the prediction at its cell exceeds 0.5
+    if (a.counts && tid < T) {
+        const int n = gcell[tid], an = n / HW, r = n - an * HW, j = r / a.W, i = r - j * a.W;
+        const long long base = ((long long)b * a.A * K + (long long)an * K) * HW + r;
+        const float px = sigmoidf_(a.out[base]) + (float)i, py = sigmoidf_(a.out[base + HW]) + (float)j;
+        const float pw = expf(expf(a.out[base + 2 * HW])) * a.aw[an], ph = expf(expf(a.out[base + 3 * HW])) * a.ah[an];
+        correct = iou_cwh(gx[tid], gy[tid], gw[tid], gh[tid], px, py, pw, ph) > 0.5f ? 1 : 0;
+        atomicAdd(a.counts, 1);
+        if (correct) atomicAdd(a.counts + 1, 1);
+    }
+    red[tid] = lsum;
+    __syncthreads();
+    for (int o = NTHR / 2; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) a.partial[b] = red[0] * inv_nb;
+}
+
+__global__ __launch_bounds__(256) void region_loss_sum_kernel(const float* partial, int B, float* loss) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = red[0];
+}
+
+extern "C" size_t mcamd_region_loss_workspace_bytes(int32_t B) { return (size_t)(B > 0 ? B : 1) * sizeof(float); }
+
+extern "C" int mcamd_region_loss(const mcamd_region_desc* d, float* loss, float* grad, int32_t* counts, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    MCAMD_REQUIRE(d && d->output && d->target && loss && grad && workspace, "region_loss: null argument");
+    MCAMD_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->num_anchors > 0 && d->num_anchors <= 8 && d->num_classes > 0,
+                  "region_loss: bad shape (B %d, %d x %d, %d anchors <= 8, %d classes)", d->B, d->H, d->W, d->num_anchors,
+                  d->num_classes);
+    MCAMD_REQUIRE(d->max_boxes == MAXT, "region_loss: target rows hold %d boxes (got %d)", MAXT, d->max_boxes);
+    if (workspace_bytes < mcamd_region_loss_workspace_bytes(d->B)) {
+        mcamd_set_error("region_loss: workspace %zu < %zu bytes", workspace_bytes, mcamd_region_loss_workspace_bytes(d->B));
+        return MCAMD_EWORKSPACE;
+    }
+    RegionArgs a;
+    a.out = d->output, a.target = d->target, a.grad = grad, a.partial = (float*)workspace, a.counts = counts;
+    a.B = d->B, a.A = d->num_anchors, a.C = d->num_classes, a.H = d->H, a.W = d->W;
+    for (int n = 0; n < 8; ++n) a.aw[n] = n < d->num_anchors ? d->anchors[2 * n] : 1.f, a.ah[n] = n < d->num_anchors ? d->anchors[2 * n + 1] : 1.f;
+    a.coord_scale = d->coord_scale, a.noobject_scale = d->noobject_scale, a.object_scale = d->object_scale;
+    a.class_scale = d->class_scale, a.thresh = d->thresh;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(region_loss_kernel, dim3(d->B), dim3(NTHR), 0, st, a);
+    hipLaunchKernelGGL(region_loss_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, d->B, loss);
+    MCAMD_LAUNCH_CHECK("region_loss");
+    return MCAMD_OK;
+}

@@ -381,6 +381,35 @@ def nchw_to_padded_split(src, dst, dst_ld, dst_choff, plane):
                                                           stream_ptr()), "mcamd_nchw_f32_to_padded_nhwc_f16_split")
 
 
+def region_loss(output, target, anchors, num_anchors, num_classes, coord_scale, noobject_scale, object_scale, class_scale, thresh,
+                want_counts=False):
+    """Loss (0-dim fp32 tensor), d(loss)/d(output) and optionally the (nGT, nCorrect) counters of the YOLOv2 region loss in
+    one library call (include/mcamd.h, mcamd_region_desc; reference nets.py:282-635)."""
+    _need_cuda(output, target)
+    assert output.dtype == torch.float32 and output.is_contiguous() and output.dim() == 4
+    B, ch, H, W = output.shape
+    if ch != num_anchors * (5 + num_classes):
+        raise L.McamdError("region_loss: %d channels, expected %d anchors x (5 + %d classes)" % (ch, num_anchors, num_classes))
+    tgt = target.detach().to(device=output.device, dtype=torch.float32).contiguous().view(B, -1)
+    if tgt.shape[1] % 5 or len(anchors) < 2 * num_anchors:
+        raise L.McamdError("region_loss: target rows must hold (class, x, y, w, h) boxes; anchors %d pairs" % num_anchors)
+    d = L.RegionDesc()
+    d.output, d.target = output.data_ptr(), tgt.data_ptr()
+    d.B, d.H, d.W, d.num_anchors, d.num_classes, d.max_boxes = B, H, W, num_anchors, num_classes, tgt.shape[1] // 5
+    step = len(anchors) // num_anchors
+    for n in range(num_anchors):
+        d.anchors[2 * n], d.anchors[2 * n + 1] = float(anchors[step * n]), float(anchors[step * n + 1])
+    d.coord_scale, d.noobject_scale, d.object_scale = float(coord_scale), float(noobject_scale), float(object_scale)
+    d.class_scale, d.thresh = float(class_scale), float(thresh)
+    loss = torch.empty((), dtype=torch.float32, device=output.device)
+    grad = torch.empty_like(output)
+    counts = torch.zeros(2, dtype=torch.int32, device=output.device) if want_counts else None
+    ws = torch.empty(int(L.lib().mcamd_region_loss_workspace_bytes(B)), dtype=torch.uint8, device=output.device)
+    check(L.lib().mcamd_region_loss(C.byref(d), ptr(loss), ptr(grad), ptr(counts), ptr(ws), ws.numel(), stream_ptr()),
+          "mcamd_region_loss")
+    return loss, grad, counts
+
+
 # ------------------------------------------------------------------ launch plans
 class Plan:
     """A recorded sequence of library calls (include/mcamd.h, "Launch plans"), replayed with one call per segment."""

@@ -84,3 +84,28 @@ def test_detections_on_device_equal_the_list_pipeline(dev):
                 ref.append(tuple(float(v) for v in box[:4]) + (int(box[6 + 2 * j]), float(box[4] * box[5 + 2 * j])))
         got = [tuple(float(v) for v in bx) + (c, float(p)) for bx, cl in dets[b] for c, p in cl]
         assert got == ref and len(got) > 1000
+
+
+def test_region_loss_hip_kernel_equals_torch_restatement(dev):
+    """csrc/region_loss.hip (loss and its gradient in one pass) against the batched torch restatement of nets.py:282-635 on the
+    same device (RegionLoss.fused = False): B=64, up to six boxes per image with shared cells, empty images, large logits."""
+    g = torch.Generator().manual_seed(11)
+    out0 = (torch.randn(64, 125, 13, 13, generator=g) * 1.5)
+    target = torch.zeros(64, 250)
+    for b in range(64):
+        for t in range(b % 7):
+            target[b, t * 5:(t + 1) * 5] = torch.tensor([float((b + t) % 20), 0.5, 0.5, 0.2 + 0.01 * t, 0.3]) if t < 2 \
+                else torch.cat((torch.tensor([float(t)]), torch.rand(4, generator=g) * 0.8 + 0.1))
+    res = {}
+    for fused in (True, False):
+        loss = RegionLoss().to(dev)
+        loss.object_scale, loss.noobject_scale, loss.class_scale, loss.coord_scale = 5.0, 1.0, 1.0, 1.0
+        loss.fused = fused
+        out = out0.clone().to(dev).requires_grad_(True)
+        val = loss(out, target.to(dev))
+        (val * 3.0).backward()                      # a non-unit upstream gradient
+        res[fused] = (float(val), out.grad.cpu())
+    assert abs(res[True][0] - res[False][0]) <= 2e-5 * abs(res[False][0]), (res[True][0], res[False][0])
+    e = float((res[True][1] - res[False][1]).norm() / res[False][1].norm())
+    print("region loss: HIP kernel %.6f, torch restatement %.6f, grad rel-L2 %.2e" % (res[True][0], res[False][0], e))
+    assert e < 1e-5
