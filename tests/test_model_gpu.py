@@ -55,12 +55,16 @@ def test_mini_train_fp16x3_vs_golden(dev):
     e = rel_l2(out.detach().cpu(), torch.from_numpy(gold["train_logits"]))
     print("mini train logits, fp16x3 forward, rel-L2 vs reference: %.2e" % e)
     assert e < 1e-3
+    # With the forward pass on split operands the ill-conditioned part of the comparison (LeakyReLU sides flipped by forward
+    # rounding) is gone: what is left is the backward pass itself -- plain fp16 operands, fp16-stored dY / G -- so the bar is
+    # ABSOLUTE here, not relative to the oracle's fp16-storage floor (2e-2 ... 7e-2 for these tensors): 5e-3 on every
+    # parameter gradient against the reference's golden run.
     _, fl_grads = _oracle_run(blocks, state, x, gout, "fp16")
     for name, p in m.named_parameters():
         ref = torch.from_numpy(gold["grad/" + name])
         ge, gf = rel_l2(p.grad.cpu(), ref), rel_l2(fl_grads[name], ref)
         print("  grad %-28s rel-L2 %.2e (fp16-storage floor %.2e)" % (name, ge, gf))
-        assert ge < 1.5 * gf + 2e-3, name
+        assert ge < 5e-3, name
     sd = m.state_dict()
     for k in sd:
         if "running_" in k:
@@ -179,6 +183,35 @@ def test_mini_masked_training_steps(dev):
     from modelcompression_amd.pruning.weightPruning.utils import are_masks_consistent, prune_rate
     assert are_masks_consistent(m, masks)
     assert prune_rate(m, verbose=False) > 50.0
+
+
+def test_mini_masked_training_steps_split_forward(dev):
+    """The same two masked SGD steps with the forward pass on split operands (precision "fp16x3"): without the forward's
+    fp16 noise the weight UPDATE must track the reference's golden run closely -- an absolute bar (5e-2 on the worst tensor;
+    2.1e-2 measured, the second step sees the first step's update error through the train-mode network; the plain-fp16
+    mode is only held to 1.5 x its 0.18 storage floor + 0.02 = 0.29), i.e. a real check of backward + SGD."""
+    gold = np.load(os.path.join(HERE, "golden", "sgd_step.npz"))
+    m, blocks, state = _mini_model(dev)
+    m.precision = "fp16x3"
+    masks = [torch.from_numpy(gold["mask%d" % i]).to(dev) for i in range(7)]
+    m.set_masks(masks)
+    start = {n: p.detach().cpu().clone() for n, p in m.named_parameters()}
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3, momentum=0.9, dampening=0, weight_decay=0.0005 * 2)
+    m.train()
+    for step in range(2):
+        out = m(torch.from_numpy(gold["x%d" % step]).to(dev))
+        opt.zero_grad()
+        out.backward(torch.from_numpy(gold["g%d" % step]).to(dev))
+        opt.step()
+    worst = 0.0
+    for name, p in m.named_parameters():
+        upd_ref = torch.from_numpy(gold["step1/" + name]) - start[name]
+        e = rel_l2(p.detach().cpu() - start[name], upd_ref)
+        worst = max(worst, e)
+    print("worst relative error of the 2-step weight update, split-operand forward: %.2e" % worst)
+    assert worst < 5e-2
+    for p, mk in zip([p for p in m.parameters() if p.dim() == 4], masks):
+        assert bool((p.detach()[mk == 0] == 0).all())
 
 
 def _teacher_forced(dev, cfg, B, seed, masked, hw=None, only=None, grad_scale=None):
