@@ -27,6 +27,14 @@
  *     layer reads 32 contiguous halfs per pixel.
  *   raw conv output / gradient wrt a block output: fp16 [B*H*W][ld] (no halo).
  *   stem input (first layer, Cin = 3): padded NHWC with ld = 4 (channel 3 zero).
+ *   activation, SHARED-HALO form (`pad` = 1 in the descriptors below; the engine uses it for its small images, W <= 26):
+ *     the same tensor with ONE zero pixel between consecutive rows and ONE zero row between consecutive images --
+ *     pixel (b, h, w) at ((b (H + 1) + h + 1) (W + 1) + w + 1) ld from a pointer that is the address of pixel
+ *     (0, -1, -1); B (H + 1) (W + 1) + W + 2 pixels in all (the last image's bottom halo row and corner), guard bands as
+ *     above.  The right halo of a row IS the left halo of the next one, the bottom halo row of an image the top one of the
+ *     next: every 3x3 tap is still a constant shift, (ty - 1)(W + 1) + (tx - 1) pixels, and every kernel's addressing stays
+ *     linear -- but the padded-pixel enumeration of the 9-tap weight gradient shrinks from (H + 2)(W + 2) to
+ *     (H + 1)(W + 1) rows per image (13x13: 225 -> 196, -13 % of its MFMA work; conv19's weight gradient -19 %).
  *   packed weights: fp16 [Npad][K], see mcamd_pack_weights.
  *   master weights, masks, weight gradients: fp32 OIHW exactly as torch holds them.
  */
@@ -67,6 +75,8 @@ typedef struct mcamd_conv_geom {
     int32_t x_ld;         /* channels per pixel of the input buffer           */
     int32_t x_choff;      /* first input channel inside the buffer            */
     int32_t stem;         /* 1: first-layer form, x is NHWC4 (x_ld == 4), cin == 3, ksize == 3 */
+    int32_t pad;          /* 0: padded NHWC; 1: shared-halo form (above) of EVERY padded operand of the call -- x in
+                             mcamd_conv_fwd, dy in mcamd_conv_dgrad, x and dy in mcamd_conv_wgrad.  stem == 0 only. */
 } mcamd_conv_geom;
 
 /* Output side of a convolution launch. */
@@ -100,6 +110,7 @@ typedef struct mcamd_conv_epilogue {
     void* y2;                  /* dst_mode POOL, may be NULL: a second, FULL-resolution padded copy of leaky(bn(conv)) (the
                                   route that reads the block beside its pool: conv13 of yolov2-voc.cfg) */
     int32_t y2_ld, y2_choff;
+    /* (mode 2 writes the standard padded form: inference engines do not use the shared-halo one) */
 } mcamd_conv_epilogue;
 
 /* Rows of the BatchNorm partial-sum slab a forward launch of this geometry writes (epilogue mode 0). */
@@ -234,6 +245,7 @@ typedef struct mcamd_act_desc {
                                   1e-3 logits (tools/error_budget.py).  Reading channels [0, C) alone is the plain
                                   fp16 activation. */
     int32_t dst_plane, dst2_plane; /* plane strides (channels, multiples of 8) of dst / dst2 when planes == 3 */
+    int32_t dst_pad, dst2_pad; /* 0 / 1: dst, dst2 are in the padded / the shared-halo form (each at its own resolution) */
     const float* border;       /* optional fp32 [16][C], NULL = none: added to the raw conv output before the
                                   affine step, row = border class of the pixel (bit 0: h == 0, bit 1: h == H-1,
                                   bit 2: w == 0, bit 3: w == W-1).  Physically slim filter-pruned models fold the
@@ -263,6 +275,7 @@ typedef struct mcamd_act_bwd_desc {
                                   as the split-storage forward keeps them) */
     int32_t* overflow;         /* optional device flag, set to 1 when a dY value was clamped to +-65504 (see
                                   mcamd_conv_epilogue.overflow) */
+    int32_t dy_pad;            /* 0 / 1: dy is in the padded / the shared-halo form */
     int32_t skip_dead_param_grads; /* n > 0: dgamma / dbeta of the physical channels c >= n are NOT written -- the
                                   consumer that folded those dead channels delivers their gradients
                                   (mcamd_unfold_wgrad) and `g` holds nothing for them; 0 = write all */
@@ -370,6 +383,10 @@ int mcamd_nchw_f32_to_padded_nhwc_f16(const float* src, int32_t B, int32_t C, in
 /* The same into split storage (mcamd_act_desc.planes == 3): channel c of the image is written as hi = fp16(v) at
  * dst_choff + c, lo = fp16(v - hi) at dst_choff + plane + c and hi again at dst_choff + 2 * plane + c -- the network
  * input of the "fp16x3" / "mixed" precision modes (nets.py:720 takes the image as fp32 NCHW). */
+/* As mcamd_nchw_f32_to_padded_nhwc_f16 with the destination in the shared-halo form when pad == 1. */
+int mcamd_nchw_f32_to_padded_nhwc_f16_pad(const float* src, int32_t B, int32_t C, int32_t H, int32_t W,
+                                          float mul, void* dst, int32_t dst_ld, int32_t dst_choff, int32_t pad,
+                                          int32_t* overflow, void* stream);
 int mcamd_nchw_f32_to_padded_nhwc_f16_split(const float* src, int32_t B, int32_t C, int32_t H, int32_t W,
                                             void* dst, int32_t dst_ld, int32_t dst_choff, int32_t plane, void* stream);
 

@@ -17,7 +17,7 @@ class McamdError(RuntimeError):
 class ConvGeom(C.Structure):
     _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("ksize", C.c_int32),
                 ("cin", C.c_int32), ("cout", C.c_int32), ("x_ld", C.c_int32), ("x_choff", C.c_int32),
-                ("stem", C.c_int32)]
+                ("stem", C.c_int32), ("pad", C.c_int32)]
 
 
 class ConvEpilogue(C.Structure):
@@ -35,7 +35,7 @@ class ActDesc(C.Structure):
                 ("dst", C.c_void_p), ("dst_ld", C.c_int32), ("dst_choff", C.c_int32),
                 ("dst2", C.c_void_p), ("dst2_ld", C.c_int32), ("dst2_choff", C.c_int32),
                 ("y_dtype", C.c_int32), ("planes", C.c_int32), ("dst_plane", C.c_int32), ("dst2_plane", C.c_int32),
-                ("border", C.c_void_p)]
+                ("dst_pad", C.c_int32), ("dst2_pad", C.c_int32), ("border", C.c_void_p)]
 
 
 class ChanMap(C.Structure):
@@ -59,7 +59,7 @@ class ActBwdDesc(C.Structure):
                 ("dy", C.c_void_p), ("dy_ld", C.c_int32), ("dy_choff", C.c_int32),
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("grad_scale", C.c_float),
                 ("dy_keep", C.c_void_p), ("chan_perm", C.c_void_p), ("y_dtype", C.c_int32),
-                ("overflow", C.c_void_p), ("skip_dead_param_grads", C.c_int32)]
+                ("overflow", C.c_void_p), ("dy_pad", C.c_int32), ("skip_dead_param_grads", C.c_int32)]
 
 
 class FoldDesc(C.Structure):
@@ -126,6 +126,7 @@ SIGNATURES = {
     "mcamd_stem_block_fwd": (C.c_int, [C.POINTER(StemBlockDesc), _P, _SZ, _P]),
     "mcamd_stem_block_bwd": (C.c_int, [C.POINTER(StemBlockDesc), _P, _SZ, _P]),
     "mcamd_nchw_f32_to_padded_nhwc_f16": (C.c_int, [_P, _I32, _I32, _I32, _I32, _F, _P, _I32, _I32, _P, _P]),
+    "mcamd_nchw_f32_to_padded_nhwc_f16_pad": (C.c_int, [_P, _I32, _I32, _I32, _I32, _F, _P, _I32, _I32, _I32, _P, _P]),
     "mcamd_nchw_f32_to_padded_nhwc_f16_split": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _P]),
     "mcamd_region_loss_workspace_bytes": (_SZ, [_I32]),
     "mcamd_region_loss": (C.c_int, [C.POINTER(RegionDesc), _P, _P, _P, _P, _SZ, _P]),

@@ -38,12 +38,20 @@ extern "C" const char* mcamd_last_error(void) { return g_err; }
 static int cin_tap_of(const mcamd_conv_geom* g) { return g->stem ? 32 : round_up_int(g->cin, 32); }
 static int ntaps_of(const mcamd_conv_geom* g) { return g->stem ? 3 : g->ksize * g->ksize; }
 static int cout_p_of(const mcamd_conv_geom* g) { return round_up_int(g->cout, 32); }
+// padded pixels per row / rows per image of the operands (2: zero halo on every side; 1: shared-halo form, mcamd.h), and
+// the number of padded pixels the 9-tap weight gradient enumerates
+static int pw_of(const mcamd_conv_geom* g) { return g->pad ? 1 : 2; }
+static long long padded_pixels(const mcamd_conv_geom* g) {
+    const int pw = pw_of(g);
+    return (long long)g->B * (g->H + pw) * (g->W + pw) + (pw == 1 ? g->W + 2 : 0);
+}
 
 static int check_geom(const mcamd_conv_geom* g, const char* what) {
     MCAMD_REQUIRE(g, "%s: null geometry", what);
     MCAMD_REQUIRE(g->B > 0 && g->H > 0 && g->W > 0 && g->cin > 0 && g->cout > 0, "%s: non-positive dimension", what);
     MCAMD_REQUIRE(g->ksize == 1 || g->ksize == 3, "%s: ksize %d unsupported (1 or 3)", what, g->ksize);
     MCAMD_REQUIRE((long long)g->B * g->H * g->W < (1ll << 31), "%s: more than 2^31 output pixels", what);
+    MCAMD_REQUIRE(g->pad == 0 || (g->pad == 1 && !g->stem), "%s: pad must be 0 or 1 (and 0 for the stem layer)", what);
     if (g->stem) {
         MCAMD_REQUIRE(g->cin == 3 && g->ksize == 3 && g->x_ld == 4 && g->x_choff == 0,
                       "%s: stem form needs cin=3, ksize=3, x_ld=4, x_choff=0", what);
@@ -378,7 +386,7 @@ static int fill_epilogue(IgemmArgs& a, const mcamd_conv_epilogue* e, int n_out, 
 extern "C" int32_t mcamd_conv_stats_rows(const mcamd_conv_geom* g) {
     if (!g) return 0;
     if (mcamd_stem_direct_ok(g->stem, g->cout, MCAMD_EPI_RAW_F16)) return mcamd_stem_rows((long long)g->B * g->H * g->W);
-    if (mcamd_wres_ok(g->ksize, g->stem, g->cout, cin_tap_of(g), ntaps_of(g) * cin_tap_of(g), g->B, g->H, g->W, MCAMD_EPI_RAW_F16))
+    if (g->pad == 0 && mcamd_wres_ok(g->ksize, g->stem, g->cout, cin_tap_of(g), ntaps_of(g) * cin_tap_of(g), g->B, g->H, g->W, MCAMD_EPI_RAW_F16))
         return mcamd_wres_rows(g->cout, g->B, g->H, g->W);
     return mcamd_igemm_rows((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g), ntaps_of(g) * cin_tap_of(g));
 }
@@ -398,7 +406,7 @@ extern "C" int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int
         out[0] = 32, out[1] = g->cout, out[2] = 48, out[3] = 1;   // stem_fwd_kernel (conv_stem.hip)
         return MCAMD_OK;
     }
-    if (!dgrad && mcamd_wres_ok(g->ksize, g->stem, g->cout, cin_tap_of(g), ntaps_of(g) * cin_tap_of(g), g->B, g->H, g->W, MCAMD_EPI_RAW_F16)) {
+    if (!dgrad && g->pad == 0 && mcamd_wres_ok(g->ksize, g->stem, g->cout, cin_tap_of(g), ntaps_of(g) * cin_tap_of(g), g->B, g->H, g->W, MCAMD_EPI_RAW_F16)) {
         out[0] = 128, out[1] = 128, out[2] = 64, out[3] = 6;   // wres_kernel (conv_wres.hip): weights resident in registers
         return MCAMD_OK;
     }
@@ -426,8 +434,8 @@ extern "C" int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const voi
     a.x = (const half_t*)x;
     a.w = (const half_t*)wp_fwd;
     a.x_ld = g->x_ld;
-    a.x_row_stride = (g->W + 2) * g->x_ld;
-    a.x_img_stride = (long long)(g->H + 2) * a.x_row_stride;
+    a.x_row_stride = (g->W + pw_of(g)) * g->x_ld;
+    a.x_img_stride = (long long)(g->H + pw_of(g)) * a.x_row_stride;
     a.x_off = g->x_choff;
     a.H = g->H, a.W = g->W, a.HW = g->H * g->W;
     a.M = g->B * g->H * g->W;
@@ -438,7 +446,7 @@ extern "C" int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const voi
     a.ktot = a.ntaps * a.cin_tap;
     fill_taps(g->ksize, g->stem, a.x_row_stride, g->x_ld, a.tap_off);
     const bool stem_direct = epi && mcamd_stem_direct_ok(g->stem, g->cout, epi->mode);
-    const bool wres = epi && epi->dst_mode == MCAMD_DST_PLAIN &&
+    const bool wres = epi && epi->dst_mode == MCAMD_DST_PLAIN && g->pad == 0 &&
                       mcamd_wres_ok(g->ksize, g->stem, g->cout, a.cin_tap, a.ktot, g->B, g->H, g->W, epi->mode);
     if (fill_epilogue(a, epi, g->cout, a.M, a.cin_tap, a.ktot, "conv_fwd",
                       stem_direct ? mcamd_stem_rows(a.M) : (wres ? mcamd_wres_rows(g->cout, g->B, g->H, g->W) : -1)))
@@ -473,8 +481,8 @@ extern "C" int mcamd_conv_dgrad(const mcamd_conv_geom* g, const void* dy, int32_
     a.x = (const half_t*)dy;
     a.w = (const half_t*)wp_dgrad;
     a.x_ld = dy_ld;
-    a.x_row_stride = (g->W + 2) * dy_ld;
-    a.x_img_stride = (long long)(g->H + 2) * a.x_row_stride;
+    a.x_row_stride = (g->W + pw_of(g)) * dy_ld;
+    a.x_img_stride = (long long)(g->H + pw_of(g)) * a.x_row_stride;
     a.x_off = dy_choff;
     a.H = g->H, a.W = g->W, a.HW = g->H * g->W;
     a.M = g->B * g->H * g->W;
@@ -499,7 +507,7 @@ static WgradPlan wgrad_plan_for(const mcamd_conv_geom* g) {
     if (mcamd_wgrad_win_ok(g->ksize, g->stem, g->cout, cin_tap_of(g), g->W, (long long)g->B * g->H * g->W))
         return mcamd_wgrad_win_plan((long long)g->B * g->H * g->W, g->cout);
     if (mcamd_wgrad_use9(g->ksize, g->stem, g->cout, cin_tap_of(g), g->W))
-        return mcamd_wgrad_plan9((long long)g->B * (g->H + 2) * (g->W + 2), g->cout, cin_tap_of(g), g->W, g->H, g->B);
+        return mcamd_wgrad_plan9(padded_pixels(g), g->cout, cin_tap_of(g), g->W, g->W + pw_of(g), g->B);
     return mcamd_wgrad_plan((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g), ntaps_of(g));
 }
 
@@ -543,12 +551,12 @@ extern "C" int mcamd_conv_wgrad(const mcamd_conv_geom* g, const void* x, const v
     a.dy = (const half_t*)dy;
     a.slab = (float*)workspace;
     a.x_ld = g->x_ld;
-    a.x_row_stride = (g->W + 2) * g->x_ld;
-    a.x_img_stride = (long long)(g->H + 2) * a.x_row_stride;
+    a.x_row_stride = (g->W + pw_of(g)) * g->x_ld;
+    a.x_img_stride = (long long)(g->H + pw_of(g)) * a.x_row_stride;
     a.x_off = g->x_choff;
     a.dy_ld = dy_ld;
-    a.dy_row_stride = (g->W + 2) * dy_ld;
-    a.dy_img_stride = (long long)(g->H + 2) * a.dy_row_stride;
+    a.dy_row_stride = (g->W + pw_of(g)) * dy_ld;
+    a.dy_img_stride = (long long)(g->H + pw_of(g)) * a.dy_row_stride;
     a.dy_off = dy_choff + a.dy_row_stride + dy_ld;
     a.dy_zero_off = dy_choff;
     a.H = g->H, a.W = g->W, a.HW = g->H * g->W;
@@ -557,7 +565,7 @@ extern "C" int mcamd_conv_wgrad(const mcamd_conv_geom* g, const void* x, const v
     a.ntaps = ntaps;
     a.ktot = ntaps * cin_tap;
     fill_taps(g->ksize, g->stem, a.x_row_stride, g->x_ld, a.tap_off);
-    int rc = p.nine    ? mcamd_wgrad9_launch(a, p, g->W, (long long)g->B * (g->H + 2) * (g->W + 2), st)
+    int rc = p.nine    ? mcamd_wgrad9_launch(a, p, g->W + pw_of(g), padded_pixels(g), st)
              : p.stemw == 1 ? mcamd_wgrad_stem_launch(a, p, st)
              : p.stemw == 2 ? mcamd_wgrad_win_launch(a, p, st)
                        : mcamd_wgrad_launch(a, p, st);
@@ -566,7 +574,7 @@ extern "C" int mcamd_conv_wgrad(const mcamd_conv_geom* g, const void* x, const v
                                    mask_oihw, 1.0f / grad_scale, dw_oihw, rmap, cmap, st);
     if (rc) return rc;
     if (dbias) {
-        long long rows = (long long)g->B * (g->H + 2) * (g->W + 2);
+        long long rows = padded_pixels(g);
         // (the split-K slabs are consumed by the finish pass enqueued above: the workspace is free again, in stream order)
         rc = mcamd_colsum_launch((const half_t*)dy, rows, dy_ld, dy_choff, g->cout, 1.0f / grad_scale, dbias, st, workspace,
                                  workspace_bytes);

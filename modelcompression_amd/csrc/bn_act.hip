@@ -102,6 +102,7 @@ struct ActArgs {
     long long items;
     const float* border;  // optional [16][C]: added to the raw conv output by border class (slim models)
     int dst_plane, dst2_plane;  // plane strides of the split (hi | lo | hi) storage, PL == 3
+    int dst_pw, dst2_pw;        // halo pixels per row / rows per image of dst, dst2: 2 (padded form) or 1 (shared-halo form)
 };
 
 __device__ __forceinline__ void load8(const half_t* p, float* v) {
@@ -148,8 +149,9 @@ __device__ __forceinline__ void store_act(half_t* p, int plane, const float* v) 
         *(h8_t*)(p + 2 * plane) = hi;
     }
 }
-__device__ __forceinline__ long long pad_off(int b, int h, int w, int H, int W, int ld) {
-    return (((long long)b * (H + 2) + h + 1) * (W + 2) + w + 1) * ld;
+// offset of pixel (b, h, w) from the buffer pointer; pw = 2: padded NHWC, pw = 1: shared-halo form (include/mcamd.h)
+__device__ __forceinline__ long long pad_off(int b, int h, int w, int H, int W, int ld, int pw = 2) {
+    return (((long long)b * (H + pw) + h + 1) * (W + pw) + w + 1) * ld;
 }
 
 // Border class of pixel (h, w): which 3x3 taps fall into the zero padding (bit 0 top, 1 bottom, 2 left, 3 right).
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(ActArgs a) {
                 float z = v[i] * sc[i] + sh[i];
                 v[i] = z > 0.f ? z : z * a.slope;
             }
-            store_act<PL>(a.dst + pad_off(b, h, w, a.H, a.W, a.dst_ld) + a.dst_choff + c8, a.dst_plane, v);
+            store_act<PL>(a.dst + pad_off(b, h, w, a.H, a.W, a.dst_ld, a.dst_pw) + a.dst_choff + c8, a.dst_plane, v);
         } else {
             int b = (int)(pix / (Ho * Wo));
             int rem = (int)(pix - (long long)b * Ho * Wo);
@@ -215,9 +217,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(ActArgs a) {
                     float z = act[k][i] * sc[i] + sh[i];
                     act[k][i] = z > 0.f ? z : z * a.slope;
                 }
-                if (a.dst2) store_act<PL>(a.dst2 + pad_off(b, h, w, a.H, a.W, a.dst2_ld) + a.dst2_choff + c8, a.dst2_plane, act[k]);
+                if (a.dst2) store_act<PL>(a.dst2 + pad_off(b, h, w, a.H, a.W, a.dst2_ld, a.dst2_pw) + a.dst2_choff + c8, a.dst2_plane, act[k]);
             }
-            long long dp = pad_off(b, ho, wo, Ho, Wo, a.dst_ld) + a.dst_choff;
+            long long dp = pad_off(b, ho, wo, Ho, Wo, a.dst_ld, a.dst_pw) + a.dst_choff;
             if (MODE == MCAMD_DST_POOL) {
                 float m[8];
 #pragma unroll
@@ -251,6 +253,7 @@ struct ActBwdArgs {
     int y_ld, y_choff, g_ld, g_choff, g2_ld, g2_choff, dy_ld, dy_choff;
     float slope;
     long long items;
+    int dy_pw;             // 2: dy in the padded form, 1: shared-halo form
 };
 
 // PHASE 0: per-channel sums of g_z and g_z*xhat -> slab.  PHASE 1: dy -> padded NHWC.
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(ActBwdArgs a) {
                 }
             }
             if (PHASE == 1) {
-                store8(a.dy + pad_off(b, hh[k], ww[k], a.H, a.W, a.dy_ld) + a.dy_choff + c8, out);
+                store8(a.dy + pad_off(b, hh[k], ww[k], a.H, a.W, a.dy_ld, a.dy_pw) + a.dy_choff + c8, out);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) sat |= fabsf(out[i]) > 65504.f;
             }
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(256) void bn_plain_bwd_kernel(ActBwdArgs a) {
             }
         }
         if (PHASE == 1) {
-            store8(a.dy + pad_off(b, h, w, a.H, a.W, a.dy_ld) + a.dy_choff + c8, out);
+            store8(a.dy + pad_off(b, h, w, a.H, a.W, a.dy_ld, a.dy_pw) + a.dy_choff + c8, out);
             w += sw_;
             if (w >= a.W) w -= a.W, ++h;
             h += sh_;
@@ -621,8 +624,8 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(ActBwdArgs a) {
             }
         }
         if (PHASE == 1) {
-            half_t* d0 = a.dy + pad_off(b, 2 * ho, 2 * wo, a.H, a.W, a.dy_ld) + a.dy_choff + c8;
-            const long long drow = (long long)(a.W + 2) * a.dy_ld;
+            half_t* d0 = a.dy + pad_off(b, 2 * ho, 2 * wo, a.H, a.W, a.dy_ld, a.dy_pw) + a.dy_choff + c8;
+            const long long drow = (long long)(a.W + a.dy_pw) * a.dy_ld;
             store8(d0, out[0]);
             store8(d0 + a.dy_ld, out[1]);
             store8(d0 + drow, out[2]);
@@ -668,7 +671,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* slab
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, int B, int C, int H, int W, float mul,
                                                            half_t* dst, int ld, int choff, int cgroups, int* overflow,
-                                                           int plane) {
+                                                           int plane, int pw) {
     bool sat = false;
     // item = (pixel, channel group of up to 8); consecutive threads -> consecutive pixels (coalesced NCHW reads)
     const long long HW = (long long)H * W;
@@ -680,7 +683,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, int
         int rem = (int)(pix - (long long)b * HW);
         int h = rem / W, w = rem - h * W;
         int c0 = (int)pg * 8;
-        half_t* d = dst + pad_off(b, h, w, H, W, ld) + choff + c0;
+        half_t* d = dst + pad_off(b, h, w, H, W, ld, pw) + choff + c0;
         const float* s = src + ((long long)b * C + c0) * HW + rem;
         int nc = C - c0 < 8 ? C - c0 : 8;
         if (overflow)
@@ -784,6 +787,8 @@ extern "C" int mcamd_bn_act_fwd(const mcamd_act_desc* d, void* stream) {
     }
     ActArgs a;
     a.dst_plane = d->dst_plane, a.dst2_plane = d->dst2_plane;
+    MCAMD_REQUIRE((d->dst_pad == 0 || d->dst_pad == 1) && (d->dst2_pad == 0 || d->dst2_pad == 1), "bn_act_fwd: dst_pad / dst2_pad must be 0 or 1");
+    a.dst_pw = d->dst_pad ? 1 : 2, a.dst2_pw = d->dst2_pad ? 1 : 2;
     a.y = d->y;
     a.scale = d->scale;
     a.shift = d->shift;
@@ -864,6 +869,8 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
     a.B = d->B, a.H = d->H, a.W = d->W, a.C = d->C;
     a.y_ld = d->y_ld, a.y_choff = d->y_choff, a.g_ld = d->g_ld, a.g_choff = d->g_choff;
     a.g2_ld = d->g2_ld, a.g2_choff = d->g2_choff, a.dy_ld = d->dy_ld, a.dy_choff = d->dy_choff;
+    MCAMD_REQUIRE(d->dy_pad == 0 || d->dy_pad == 1, "bn_act_bwd: dy_pad must be 0 or 1");
+    a.dy_pw = d->dy_pad ? 1 : 2;
     a.slope = d->slope;
     long long pixels = (long long)d->B * d->H * d->W;
     double count = (double)pixels;
@@ -944,8 +951,26 @@ extern "C" int mcamd_nchw_f32_to_padded_nhwc_f16(const float* src, int32_t B, in
     int cgroups = (C + 7) / 8;
     long long items = (long long)B * H * W * cgroups;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(stream_grid(items)), dim3(256), 0, (hipStream_t)stream, src, B, C, H, W,
-                       mul, (half_t*)dst, dst_ld, dst_choff, cgroups, (int*)overflow, 0);
+                       mul, (half_t*)dst, dst_ld, dst_choff, cgroups, (int*)overflow, 0, 2);
     MCAMD_LAUNCH_CHECK("nchw_to_nhwc");
+    return MCAMD_OK;
+}
+
+extern "C" int mcamd_nchw_f32_to_padded_nhwc_f16_pad(const float* src, int32_t B, int32_t C, int32_t H, int32_t W, float mul,
+                                                     void* dst, int32_t dst_ld, int32_t dst_choff, int32_t pad,
+                                                     int32_t* overflow, void* stream) {
+    if (mcamd_recording())
+        return mcamd_rec_push(stream, [=](void* s) {
+            return mcamd_nchw_f32_to_padded_nhwc_f16_pad(src, B, C, H, W, mul, dst, dst_ld, dst_choff, pad, overflow, s);
+        });
+    MCAMD_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && (pad == 0 || pad == 1), "nchw_to_nhwc_pad: bad argument");
+    MCAMD_REQUIRE(dst_choff + C <= dst_ld && dst_ld != 4, "nchw_to_nhwc_pad: channel slice exceeds ld (and not the stem image)");
+    MCAMD_REQUIRE((C >= 8) ? (dst_ld % 8 == 0 && dst_choff % 8 == 0) : true, "nchw_to_nhwc_pad: alignment");
+    int cgroups = (C + 7) / 8;
+    long long items = (long long)B * H * W * cgroups;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(stream_grid(items)), dim3(256), 0, (hipStream_t)stream, src, B, C, H, W,
+                       mul, (half_t*)dst, dst_ld, dst_choff, cgroups, (int*)overflow, 0, pad ? 1 : 2);
+    MCAMD_LAUNCH_CHECK("nchw_to_nhwc_pad");
     return MCAMD_OK;
 }
 
@@ -962,7 +987,7 @@ extern "C" int mcamd_nchw_f32_to_padded_nhwc_f16_split(const float* src, int32_t
     int cgroups = (C + 7) / 8;
     long long items = (long long)B * H * W * cgroups;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(stream_grid(items)), dim3(256), 0, (hipStream_t)stream, src, B, C, H, W,
-                       1.0f, (half_t*)dst, dst_ld, dst_choff, cgroups, (int*)nullptr, plane);
+                       1.0f, (half_t*)dst, dst_ld, dst_choff, cgroups, (int*)nullptr, plane, 2);
     MCAMD_LAUNCH_CHECK("nchw_to_nhwc_split");
     return MCAMD_OK;
 }

@@ -270,7 +270,7 @@ struct Wgrad9Args {
     const half_t* dy;    // padded pixel (0,0,0), channel dy_off
     float* slab;
     int x_ld, dy_ld, x_off, dy_off;
-    int W2;              // W + 2
+    int W2;              // padded pixels per image row: W + 2 (W + 1 in the shared-halo form)
     int S;               // halo rows of the window on each side (multiple of 4, >= W + 3)
     int P;               // number of padded pixels B*(H+2)*(W+2)
     int rows_pad, ktot, cin_tap;
@@ -750,10 +750,10 @@ static int pick_kp(int tmo, int tnc, int taps) {
     return 32;
 }
 
-static int wgrad9_S(int W) { return round_up_int(W + 3, 4); }
+static int wgrad9_S(int pitch) { return round_up_int(pitch + 1, 4); }   // pitch = padded pixels per image row (W + 2, or W + 1 in the shared-halo form)
 
 // plan of the padded-pixel 9-tap kernel (see wgrad9_kernel); P = padded pixels
-static WgradPlan wgrad9_plan(long long P, int cout, int cin_tap, int W, int H, int B) {
+static WgradPlan wgrad9_plan(long long P, int cout, int cin_tap, int W, int pitch, int B) {
     WgradPlan p;
     memset(&p, 0, sizeof(p));
     p.nine = 1;
@@ -766,7 +766,7 @@ static WgradPlan wgrad9_plan(long long P, int cout, int cin_tap, int W, int H, i
     {
         const int want = MCAMD_ENV_INT("MCAMD_WGRAD9_KP", 64);   // 128 (13x13 layers only) measured 1.8x SLOWER
         for (int kp = 64; kp <= want && kp <= 128; kp *= 2)
-            if (2 * (size_t)(kp + kp + 2 * wgrad9_S(W)) * 128 <= 72 * 1024) p.kp = kp;   // two workgroups per CU: 2 x 72 KB
+            if (2 * (size_t)(kp + kp + 2 * wgrad9_S(pitch)) * 128 <= 72 * 1024) p.kp = kp;   // two workgroups per CU: 2 x 72 KB
     }
     p.rows_pad = round_up_int(cout, 64);
     p.n_otiles = p.rows_pad / 64;
@@ -778,7 +778,7 @@ static WgradPlan wgrad9_plan(long long P, int cout, int cin_tap, int W, int H, i
     // narrow kernel already executes ~1.1 PFLOP/s of padded-pixel MFMAs there: 33 % of the rows are halo at 13x13)
     // and conv22 (20 channel tiles) is 35 % slower, so the wide form is used from 40 pixels per row up
     const bool wide = cout % 128 == 0 && MCAMD_ENV_INT("MCAMD_WGRAD9W", 1) && W >= MCAMD_ENV_INT("MCAMD_WGRAD9W_MINW", 40) &&
-                      2 * (size_t)(64 * 256 + (64 + 2 * wgrad9_S(W)) * 128) <= 160 * 1024;
+                      2 * (size_t)(64 * 256 + (64 + 2 * wgrad9_S(pitch)) * 128) <= 160 * 1024;
     if (wide) {
         p.nine = 2;
         p.tmo = 128;
@@ -815,9 +815,10 @@ bool mcamd_wgrad_use9(int ksize, int stem, int cout, int cin_tap, int W) {
            W <= MCAMD_ENV_INT("MCAMD_WGRAD9_MAXW", 208) && MCAMD_ENV_INT("MCAMD_WGRAD9", 1);
 }
 
-WgradPlan mcamd_wgrad_plan9(long long P, int cout, int cin_tap, int W, int H, int B) { return wgrad9_plan(P, cout, cin_tap, W, H, B); }
+WgradPlan mcamd_wgrad_plan9(long long P, int cout, int cin_tap, int W, int pitch, int B) { return wgrad9_plan(P, cout, cin_tap, W, pitch, B); }
 
-int mcamd_wgrad9_launch(const WgradArgs& w, const WgradPlan& p, int W, long long P, hipStream_t st) {
+// pitch: padded pixels per image row; P: padded pixels enumerated (both follow the operands' form, include/mcamd.h)
+int mcamd_wgrad9_launch(const WgradArgs& w, const WgradPlan& p, int pitch, long long P, hipStream_t st) {
     Wgrad9Args a;
     memset(&a, 0, sizeof(a));
     a.x = w.x;
@@ -827,8 +828,8 @@ int mcamd_wgrad9_launch(const WgradArgs& w, const WgradPlan& p, int W, long long
     a.dy_ld = w.dy_ld;
     a.x_off = w.x_off;
     a.dy_off = w.dy_zero_off;          // padded pixel (0,0): the padded enumeration starts there
-    a.W2 = W + 2;
-    a.S = wgrad9_S(W);
+    a.W2 = pitch;
+    a.S = wgrad9_S(pitch);
     a.P = (int)P;
     a.rows_pad = p.rows_pad;
     a.ktot = w.ktot;

@@ -84,8 +84,8 @@ bool mcamd_wgrad_win_ok(int ksize, int stem, int cout, int cin_tap, int W, long 
 WgradPlan mcamd_wgrad_win_plan(long long M, int cout);
 int mcamd_wgrad_win_launch(WgradArgs& a, const WgradPlan& p, hipStream_t st);
 bool mcamd_wgrad_use9(int ksize, int stem, int cout, int cin_tap, int W);
-WgradPlan mcamd_wgrad_plan9(long long P, int cout, int cin_tap, int W, int H, int B);
-int mcamd_wgrad9_launch(const WgradArgs& w, const WgradPlan& p, int W, long long P, hipStream_t st);
+WgradPlan mcamd_wgrad_plan9(long long P, int cout, int cin_tap, int W, int pitch, int B);
+int mcamd_wgrad9_launch(const WgradArgs& w, const WgradPlan& p, int pitch, long long P, hipStream_t st);
 int mcamd_wgrad_finish_launch(const float* slab, const WgradPlan& p, int ktot, int cin_tap, int stem, int Cout, int Cin,
                               int ksize, const float* mask, float inv_scale, float* dw, const int* rmap, const int* cmap,
                               hipStream_t st);

@@ -106,7 +106,7 @@ def _probe_side_stream(device, tries=8):
 
 
 class Engine:
-    def __init__(self, model, B, H, W, device, grad_scale=256.0, precision="fp16", for_training=False):
+    def __init__(self, model, B, H, W, device, grad_scale=256.0, precision="fp16", for_training=False, train_layout=False):
         """`precision`: "fp16" -- fp16 MFMA operands everywhere (the throughput mode); "fp16x3" -- every conv block
         multiplies split operands (x_hi*w_hi + x_lo*w_hi + x_hi*w_lo, fp32 accumulate: three fp16 MFMA products per
         multiply, ~2^-21 operand precision), activations are stored as hi | lo pairs and the raw conv output as fp32;
@@ -118,6 +118,7 @@ class Engine:
         self.model, self.B, self.device = model, B, device
         self.precision = precision
         self.for_training = bool(for_training)
+        self.train_layout = bool(train_layout)     # built by a model in training mode: forward(training=True) only
         self.precise = precision != "fp16"
         self.grad_scale = float(grad_scale)
         self.serial = 0
@@ -216,9 +217,21 @@ class Engine:
         place = {}
         self.bufs = []
 
+        # Small images (W <= 26: the 26x26 and 13x13 tensors of YOLOv2) live in the SHARED-HALO form (include/mcamd.h): the
+        # 9-tap weight gradient enumerates (H + 1)(W + 1) instead of (H + 2)(W + 2) padded pixels per image (13x13: -13 % of
+        # its MFMA work, conv19's launch -19 %); every other kernel only sees a different row pitch.  Training engines on
+        # plain fp16 operands only (inference and the split-operand modes keep the padded form).
+        self.shared_halo_maxw = 0
+        if self.train_layout and not self.precise and os.environ.get("MCAMD_SHARED_HALO", "1") == "1":
+            self.shared_halo_maxw = int(os.environ.get("MCAMD_SHARED_HALO_MAXW", "26"))
+
+        def pad_for(w):
+            return 1 if (w <= self.shared_halo_maxw and w >= 4) else 0
+
         def new_buf(Bn, h, w, ld):
-            self.bufs.append(ops.alloc_padded(Bn, h, w, ld, dev))
+            self.bufs.append(ops.alloc_padded(Bn, h, w, ld, dev, pad=pad_for(w)))
             return len(self.bufs) - 1
+        self._pad_for = pad_for
 
         planes = 3 if self.precise else 1      # split (hi | lo | hi) activation storage
 
@@ -291,7 +304,8 @@ class Engine:
             if pad != (lay.k - 1) // 2 or lay.k not in (1, 3):
                 raise NotImplementedError("conv block %d: only 'same' 1x1/3x3 convolutions" % ci)
             lay.stem = 1 if (li == 0 and self.stem) else 0
-            lay.geom = ops.geom(B, lay.H, lay.W, lay.k, lay.cin, lay.cout, tin.ld, tin.choff, lay.stem)
+            lay.pad = 0 if lay.stem else pad_for(lay.W)        # form of this block's padded operands (input and dY)
+            lay.geom = ops.geom(B, lay.H, lay.W, lay.k, lay.cin, lay.cout, tin.ld, tin.choff, lay.stem, lay.pad)
             lay.level = 1     # operand terms of the forward product: 1 plain, 3 = x_hi*w_hi + x_lo*w_hi + x_hi*w_lo
             lay.M = B * lay.H * lay.W
             lay.mode, lay.out_id, lay.out2_id = fused[ci]
@@ -373,7 +387,7 @@ class Engine:
             g = lay.geom
             # forward geometry: the K-concatenated problem [x_hi | x_lo | x_hi] x [w_hi | w_hi | w_lo]
             lay.geom_f = g if lay.level == 1 else ops.geom(B, lay.H, lay.W, lay.k, lay.level * lay.cin, lay.cout,
-                                                           lay.tin.ld, 0, 0)
+                                                           lay.tin.ld, 0, 0, lay.pad)
             nf, _ = ops.packed_elems(lay.geom_f)
             _, nd = ops.packed_elems(g)
             # zero-initialised: the one-launch packer writes real entries only (pad rows / channels stay zero)
@@ -399,7 +413,7 @@ class Engine:
                 lay.sh_dst = ops.alloc_padded(B, lay.H // 2, lay.W // 2, 32, dev)          # scratch pooled output
                 lay.sh_coef = [torch.empty(lay.cout, **f32) for _ in range(4)]             # scale, shift, mean, invstd
                 lay.stem_ws = torch.empty(ops.stem_block_workspace_bytes(), dtype=torch.uint8, device=dev)
-            lay.dy = None if (lay.fused_stem or lay.stem_shadow) else ops.alloc_padded(B, lay.H, lay.W, lay.cout_p, dev)
+            lay.dy = None if (lay.fused_stem or lay.stem_shadow) else ops.alloc_padded(B, lay.H, lay.W, lay.cout_p, dev, pad=lay.pad)
             lay.keep, lay.keep_key = None, None
             lay.gin = None
             if lay.li > 0:
@@ -662,7 +676,7 @@ class Engine:
                 lay.perm32 = perm.to(torch.int32).contiguous() if perm is not None else None
                 lay.keep = None if keep is None else (keep[perm].contiguous() if perm is not None else keep)
                 lay.geom_act = lay.geom if perm is None else ops.geom(self.B, lay.H, lay.W, lay.k, lay.cin, n_act,
-                                                                      lay.tin.ld, lay.tin.choff, lay.stem)
+                                                                      lay.tin.ld, lay.tin.choff, lay.stem, lay.pad)
                 lay.gather = perm is not None or in_perm is not None
                 lay.g_rows = perm[:n_act].to(torch.int32).contiguous() if perm is not None else None
                 lay.g_cols = in_perm.to(torch.int32).contiguous() if in_perm is not None else None
@@ -744,7 +758,7 @@ class Engine:
                 c.fold = prod
                 c.fold_cin = prod.n_act
                 c.fold_aug = min(aug, ops.round_up(prod.cout, 8))      # padding columns: zero weights
-                c.geom_act = ops.geom(self.B, c.H, c.W, c.k, c.fold_aug, c.n_act, c.tin.ld, c.tin.choff, 0)
+                c.geom_act = ops.geom(self.B, c.H, c.W, c.k, c.fold_aug, c.n_act, c.tin.ld, c.tin.choff, 0, c.pad)
                 c.gather = True
                 c.waug = torch.zeros(c.n_act, c.fold_aug, c.k, c.k, dtype=torch.float32, device=dev)
                 c.dwaug = torch.zeros_like(c.waug)
@@ -780,6 +794,9 @@ class Engine:
         B = self.B
         if tuple(x.shape) != (B, self.layers[0].cin, self.layers[0].H, self.layers[0].W):
             raise McamdError("engine built for input %s, got %s" % ((B, self.layers[0].cin, self.layers[0].H, self.layers[0].W), tuple(x.shape)))
+        if bool(training) != self.train_layout and self.shared_halo_maxw:
+            raise McamdError("this engine was planned for %s (activation layout); build one for the other mode"
+                             % ("training" if self.train_layout else "inference"))
         if training:
             for lay in self.layers:
                 if lay.border is not None:
@@ -871,7 +888,8 @@ class Engine:
                                self.bufs[t.buf], t.ld, t.choff,
                                self.bufs[t2.buf] if t2 is not None else None,
                                t2.ld if t2 is not None else 0, t2.choff if t2 is not None else 0, border=lay.border,
-                               planes=3, dst_plane=t.ps, dst2_plane=t2.ps if t2 is not None else 0)
+                               planes=3, dst_plane=t.ps, dst2_plane=t2.ps if t2 is not None else 0,
+                               dst_pad=self._pad_for(t.W), dst2_pad=self._pad_for(t2.W) if t2 is not None else 0)
                 continue
             if (not training and self.fuse_eval and lay.perm is None and lay.border is None
                     and (lay.out2_t is None or lay.mode == L.DST_POOL)
@@ -896,7 +914,8 @@ class Engine:
             ops.bn_act_fwd(B, lay.H, lay.W, lay.n_act if lay.bn_narrow else lay.cout, lay.y, lay.cout, 0, lay.scale, lay.shift,
                            lay.slope, lay.mode, self.bufs[t.buf], t.ld, t.choff,
                            self.bufs[t2.buf] if t2 is not None else None,
-                           t2.ld if t2 is not None else 0, t2.choff if t2 is not None else 0, border=lay.border)
+                           t2.ld if t2 is not None else 0, t2.choff if t2 is not None else 0, border=lay.border,
+                           dst_pad=self._pad_for(t.W), dst2_pad=self._pad_for(t2.W) if t2 is not None else 0)
 
     # ------------------------------------------------------------------ backward
     def bn_act_bwd_layer(self, lay, g, g_ld, g_choff, g2, g2_ld, g2_choff, dy, dgamma, dbeta, grad_scale):
@@ -908,7 +927,7 @@ class Engine:
                        lay.invstd, lay.slope, lay.mode, g, g_ld, g_choff, dy, lay.cout_p, 0,
                        dgamma, dbeta, grad_scale, g2, g2_ld, g2_choff,
                        self.bwd_ws, None if lay.keep is None else lay.keep[:cb], None if lay.perm32 is None else lay.perm32[:cb],
-                       overflow=self.overflow, skip_dead_from=lay.n_act if lay.skip_dead else 0)
+                       overflow=self.overflow, skip_dead_from=lay.n_act if lay.skip_dead else 0, dy_pad=lay.pad)
 
     def backward(self, grad_out, on_ready=None):
         """grad wrt the returned logits -> one flat fp32 gradient buffer; returns per-parameter views.
@@ -1051,7 +1070,7 @@ class Engine:
                 ready(lay)
                 continue
             if lay.is_last:
-                ops.nchw_to_padded(self._gout, lay.dy, lay.cout_p, 0, S, overflow=self.overflow)
+                ops.nchw_to_padded(self._gout, lay.dy, lay.cout_p, 0, S, overflow=self.overflow, pad=lay.pad)
             else:
                 cons = self.consumer_of[lay.out_id]
                 t = lay.out_t

@@ -309,12 +309,15 @@ class Darknet(nn.Module):
             prec = "fp16" if self.training else "mixed"
         # "mixed" has two budgets: the training-mode forward amplifies operand rounding of the early blocks (engine.py)
         for_training = bool(self.training and prec == "mixed")
-        key = (tuple(x.shape), x.device.index, float(self.grad_scale), prec, for_training)
+        # training and inference engines differ in their activation layout (the small images of a training engine are in the
+        # shared-halo form, engine.py), so each mode has its own
+        key = (tuple(x.shape), x.device.index, float(self.grad_scale), prec, for_training, bool(self.training))
         eng = self._engines.get(key)
         if eng is None:
             if len(self._engines) >= 3:
                 self._engines.pop(next(iter(self._engines)))
-            eng = Engine(self, x.shape[0], x.shape[2], x.shape[3], x.device, self.grad_scale, prec, for_training)
+            eng = Engine(self, x.shape[0], x.shape[2], x.shape[3], x.device, self.grad_scale, prec, for_training,
+                         train_layout=bool(self.training))
             self._engines[key] = eng
         return eng
 

@@ -32,21 +32,41 @@ def guard_elems(W, ld):
     return (round_up(W + 3, 4) + 128) * ld + SLACK
 
 
-def alloc_padded(B, H, W, ld, device):
+_PAD_OF = {}     # data_ptr of a buffer from alloc_padded -> its form (0 padded, 1 shared-halo): padded_view finds it there
+
+
+def alloc_padded(B, H, W, ld, device, pad=0):
     """Zeroed padded-NHWC fp16 buffer [B][H+2][W+2][ld], flat, with zeroed guard bands on both sides
-    (the returned tensor is a view starting at padded pixel (0,0,0); its storage holds the guards)."""
-    n = B * (H + 2) * (W + 2) * ld
+    (the returned tensor is a view starting at padded pixel (0,0,0); its storage holds the guards).
+    pad=1: the SHARED-HALO form (include/mcamd.h): B (H+1) (W+1) + W + 2 pixels, the pointer is pixel (0, -1, -1)."""
+    n = (B * (H + 1) * (W + 1) + W + 2) * ld if pad else B * (H + 2) * (W + 2) * ld
     g = guard_elems(W, ld)
     full = torch.zeros(g + n + g, dtype=HALF, device=device)
-    return full[g:g + n + SLACK]
+    buf = full[g:g + n + SLACK]
+    if pad:
+        _PAD_OF[buf.data_ptr()] = 1
+    else:
+        _PAD_OF.pop(buf.data_ptr(), None)
+    return buf
 
 
-def padded_view(buf, B, H, W, ld):
+def pad_of(buf):
+    return _PAD_OF.get(buf.data_ptr(), 0)
+
+
+def padded_view(buf, B, H, W, ld, pad=None):
+    """[B][H+2][W+2][ld] view of a buffer from alloc_padded, pixel (h, w) at [:, h + 1, w + 1].  For the shared-halo form
+    it is an OVERLAPPING strided view (a row's right halo pixel is the next row's left one): reads are what they look
+    like; write interior pixels, or zeros to halo pixels, only."""
+    if pad is None:
+        pad = pad_of(buf)
+    if pad:
+        return torch.as_strided(buf, (B, H + 2, W + 2, ld), ((H + 1) * (W + 1) * ld, (W + 1) * ld, ld, 1))
     return buf[: B * (H + 2) * (W + 2) * ld].view(B, H + 2, W + 2, ld)
 
 
-def geom(B, H, W, ksize, cin, cout, x_ld, x_choff=0, stem=0):
-    return ConvGeom(B, H, W, ksize, cin, cout, x_ld, x_choff, stem)
+def geom(B, H, W, ksize, cin, cout, x_ld, x_choff=0, stem=0, pad=0):
+    return ConvGeom(B, H, W, ksize, cin, cout, x_ld, x_choff, stem, pad)
 
 
 def packed_elems(g):
@@ -263,13 +283,14 @@ def unfold_wgrad(w, mask, rows, cols, beta, slope, n, cin_k, dwaug, dw, prod_dbe
 
 
 def bn_act_fwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, slope, mode, dst, dst_ld, dst_choff=0, dst2=None,
-               dst2_ld=0, dst2_choff=0, border=None, planes=1, dst_plane=0, dst2_plane=0):
+               dst2_ld=0, dst2_choff=0, border=None, planes=1, dst_plane=0, dst2_plane=0, dst_pad=0, dst2_pad=0):
     """`border`: optional fp32 [16, C] table added to the raw conv output by border class (slim models).
     `y` may be fp16 or fp32 (conv_fwd_raw / conv_fwd_raw32).  planes=3: split (hi | lo | hi) activation storage of
     the "fp16x3" precision mode with plane strides dst_plane / dst2_plane (include/mcamd.h, mcamd_act_desc.planes)."""
     d = ActDesc()
     d.y_dtype = 1 if y.dtype == torch.float32 else 0
     d.planes, d.dst_plane, d.dst2_plane = planes, dst_plane, dst2_plane
+    d.dst_pad, d.dst2_pad = dst_pad, dst2_pad
     d.B, d.H, d.W, d.C = B, H, W, C_
     d.y, d.y_ld, d.y_choff = y.data_ptr(), y_ld, y_choff
     d.scale, d.shift, d.slope, d.mode = scale.data_ptr(), shift.data_ptr(), slope, mode
@@ -285,9 +306,10 @@ def bn_act_fwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, slope, mode, dst, ds
 
 def bn_act_bwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, mean, invstd, slope, mode, g, g_ld, g_choff, dy, dy_ld,
                dy_choff, dgamma, dbeta, grad_scale=1.0, g2=None, g2_ld=0, g2_choff=0, workspace=None, dy_keep=None,
-               perm=None, overflow=None, skip_dead_from=0):
+               perm=None, overflow=None, skip_dead_from=0, dy_pad=0):
     d = ActBwdDesc()
     d.skip_dead_param_grads = int(skip_dead_from)
+    d.dy_pad = dy_pad
     d.B, d.H, d.W, d.C = B, H, W, C_
     d.y, d.y_ld, d.y_choff = y.data_ptr(), y_ld, y_choff
     d.scale, d.shift, d.mean, d.invstd = scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr()
@@ -363,11 +385,15 @@ def stem_block_bwd(B, H, W, x, wp, gamma, scale, shift, mean, invstd, slope, g, 
     check(L.lib().mcamd_stem_block_bwd(C.byref(d), ptr(workspace), workspace.numel(), stream_ptr()), "mcamd_stem_block_bwd")
 
 
-def nchw_to_padded(src, dst, dst_ld, dst_choff=0, mul=1.0, overflow=None):
-    """fp32 NCHW tensor -> channels [choff, choff+C) of a padded NHWC fp16 buffer."""
+def nchw_to_padded(src, dst, dst_ld, dst_choff=0, mul=1.0, overflow=None, pad=0):
+    """fp32 NCHW tensor -> channels [choff, choff+C) of a padded NHWC fp16 buffer (pad=1: shared-halo form)."""
     _need_cuda(src, dst)
     assert src.dtype == torch.float32 and src.is_contiguous()
     B, C_, H, W = src.shape
+    if pad:
+        check(L.lib().mcamd_nchw_f32_to_padded_nhwc_f16_pad(ptr(src), B, C_, H, W, mul, ptr(dst), dst_ld, dst_choff, 1,
+                                                            ptr(overflow), stream_ptr()), "mcamd_nchw_f32_to_padded_nhwc_f16_pad")
+        return
     check(L.lib().mcamd_nchw_f32_to_padded_nhwc_f16(ptr(src), B, C_, H, W, mul, ptr(dst), dst_ld, dst_choff,
                                                     ptr(overflow), stream_ptr()), "mcamd_nchw_f32_to_padded_nhwc_f16")
 

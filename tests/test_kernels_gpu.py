@@ -724,3 +724,51 @@ def test_conv_fwd_padded_pool_reorg_epilogue(dev, B, H, W, cin, cout, mode, dual
         assert halo_is_zero(dst2, B, H, W, ops.round_up(cout + 32, 32))
         # the pooled output is exactly the maximum of the stored full-resolution values
         assert torch.equal(got, F.max_pool2d(got2, 2, 2))
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,k", [(4, 13, 13, 128, 192, 3), (3, 26, 26, 64, 128, 3), (5, 13, 13, 256, 64, 1),
+                                              (2, 9, 11, 96, 320, 3), (3, 26, 26, 256, 512, 3)])
+def test_shared_halo_form_equals_padded_form(dev, B, H, W, cin, cout, k):
+    """The shared-halo activation form (include/mcamd.h: one zero pixel between rows, one zero row between images; the
+    training engine's layout for W <= 26) against the padded form on the same data: layout kernel, conv forward and dgrad
+    (bit-identical: same K order), weight gradient (the 9-tap kernel enumerates fewer padded pixels: fp32 summation order
+    only), BatchNorm + LeakyReLU forward into a shared-halo destination (bit-identical), its backward into a shared-halo dY."""
+    from modelcompression_amd import _lib as L
+    x, w = _rand_case(B, H, W, cin, cout, k, seed=41)
+    gen = torch.Generator().manual_seed(42)
+    gy = torch.randn(B, cout, H, W, generator=gen)
+    res = {}
+    for pad in (0, 1):
+        xb, ld = to_padded(x.to(dev), pad=pad)
+        assert torch.equal(padded_to_nchw(xb, B, H, W, ld, cin), q16(x)) and halo_is_zero(xb, B, H, W, ld)
+        g = ops.geom(B, H, W, k, cin, cout, ld, pad=pad)
+        wp, wd = ops.pack_weights(g, w.to(dev).contiguous())
+        y = torch.zeros(B * H * W * cout, dtype=torch.float16, device=dev)
+        stats = torch.zeros(ops.stats_rows(g), 2, ops.round_up(cout, 256), device=dev)
+        ops.conv_fwd_raw(g, xb, wp, y, cout, 0, stats)
+        dyb, dy_ld = to_padded(gy.to(dev), pad=pad)
+        dx = torch.zeros(B * H * W * ld, dtype=torch.float16, device=dev)
+        ops.conv_dgrad_raw(g, dyb, dy_ld, 0, wd, dx, ld)
+        dw = torch.full((cout, cin, k, k), float("nan"), device=dev)
+        ops.conv_wgrad(g, xb, dyb, dy_ld, 0, dw, None, 1.0, None)
+        # BatchNorm + LeakyReLU forward into a padded destination of the same form, and its backward into dY
+        scale, shift = (torch.rand(cout, generator=torch.Generator().manual_seed(1)) + 0.5).to(dev), torch.zeros(cout, device=dev)
+        dst = ops.alloc_padded(B, H, W, ops.round_up(cout, 32), dev, pad=pad)
+        ops.bn_act_fwd(B, H, W, cout, y, cout, 0, scale, shift, 0.1, L.DST_PLAIN, dst, ops.round_up(cout, 32), 0, dst_pad=pad)
+        mean, invstd = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+        gbuf = torch.randn(B * H * W * cout, generator=torch.Generator().manual_seed(2)).half().to(dev)
+        dyo = ops.alloc_padded(B, H, W, ops.round_up(cout, 32), dev, pad=pad)
+        dg, db = torch.zeros(cout, device=dev), torch.zeros(cout, device=dev)
+        if cout // 8 <= 256 and 256 % (cout // 8) == 0:
+            ops.bn_act_bwd(B, H, W, cout, y, cout, 0, scale, shift, mean, invstd, 0.1, L.DST_PLAIN, gbuf, cout, 0, dyo,
+                           ops.round_up(cout, 32), 0, dg, db, 1.0, dy_pad=pad)
+        res[pad] = (y, stats.sum(0), dx, dw, padded_to_nchw(dst, B, H, W, ops.round_up(cout, 32), cout),
+                    padded_to_nchw(dyo, B, H, W, ops.round_up(cout, 32), cout), dg, db)
+        assert halo_is_zero(dst, B, H, W, ops.round_up(cout, 32)) and halo_is_zero(dyo, B, H, W, ops.round_up(cout, 32))
+    a, b = res[0], res[1]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]), "conv forward / dgrad differ between the two forms"
+    assert torch.allclose(a[1], b[1], rtol=1e-5, atol=1e-3)
+    assert rel_l2(b[3].cpu(), a[3].cpu()) < 1e-5
+    ref = torch.nn.grad.conv2d_weight(q16(x), (cout, cin, k, k), q16(gy), padding=(k - 1) // 2)
+    assert rel_l2(b[3].cpu(), ref) < TOL
+    assert torch.equal(a[4], b[4]) and torch.equal(a[5], b[5]) and torch.equal(a[6], b[6]) and torch.equal(a[7], b[7])

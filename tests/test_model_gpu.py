@@ -423,7 +423,7 @@ def _teacher_forced(dev, cfg, B, seed, masked, hw=None, only=None, grad_scale=No
                     return t if perm is None else t[:, perm.cpu()]
                 gbuf = nchw_to_raw(phys(G, operm) * S, cons.tin.ld, ot.choff)
                 g2buf = nchw_to_raw(phys(G2, lay.perm) * S, c2.tin.ld, t2.choff) if G2 is not None else None
-                eng_dy = ops.alloc_padded(B, lay.H, lay.W, lay.cout_p, dev)
+                eng_dy = ops.alloc_padded(B, lay.H, lay.W, lay.cout_p, dev, pad=lay.pad)
                 eng_dg, eng_db = lay.bn.weight.grad.clone(), lay.bn.bias.grad.clone()
                 eng.bn_act_bwd_layer(lay, gbuf, cons.tin.ld, ot.choff, g2buf, c2.tin.ld if c2 is not None else 0,
                                      t2.choff if t2 is not None else 0, eng_dy, eng_dg, eng_db, S)

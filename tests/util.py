@@ -9,13 +9,13 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def to_padded(x, ld=None, choff=0, mul=1.0):
-    """fp32 NCHW (cuda) -> padded NHWC fp16 flat buffer via the product's layout kernel."""
+def to_padded(x, ld=None, choff=0, mul=1.0, pad=0):
+    """fp32 NCHW (cuda) -> padded NHWC fp16 flat buffer via the product's layout kernel (pad=1: shared-halo form)."""
     B, C, H, W = x.shape
     if ld is None:
         ld = 4 if C == 3 else ops.round_up(C, 32)
-    buf = ops.alloc_padded(B, H, W, ld, x.device)
-    ops.nchw_to_padded(x.contiguous(), buf, ld, choff, mul)
+    buf = ops.alloc_padded(B, H, W, ld, x.device, pad=pad)
+    ops.nchw_to_padded(x.contiguous(), buf, ld, choff, mul, pad=pad)
     return buf, ld
 
 
