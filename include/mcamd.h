@@ -167,7 +167,11 @@ typedef struct mcamd_pack_job {
     const int32_t* cols;
     int64_t first_tile;        /* sum of ceil(cout/32)*ceil(cin/32) over the preceding jobs */
     int32_t cout, cin, ksize;  /* physical geometry */
-    int32_t reserved;
+    int32_t split;             /* 0: plain fp16 forward packing.  1: the split-operand forward packing of the "fp16x3" /
+                                  "mixed" precisions, [w_hi | w_hi | w_lo] along the input channels of a 3 * cin wide row
+                                  (w_hi = fp16(w * mask), w_lo = fp16(w * mask - w_hi)), to be multiplied with
+                                  [x_hi | x_lo | x_hi] activation planes; dst_fwd then has the size of a geometry with
+                                  3 * cin input channels.  The dgrad packing is plain in both cases. */
 } mcamd_pack_job;
 int mcamd_pack_weights_many(const mcamd_pack_job* jobs_dev, int32_t njobs, int64_t total_tiles, void* stream);
 
@@ -380,15 +384,27 @@ int mcamd_stem_block_bwd(const mcamd_stem_block_desc* d, void* workspace, size_t
 int mcamd_nchw_f32_to_padded_nhwc_f16(const float* src, int32_t B, int32_t C, int32_t H, int32_t W,
                                       float mul, void* dst, int32_t dst_ld, int32_t dst_choff, int32_t* overflow,
                                       void* stream);
-/* The same into split storage (mcamd_act_desc.planes == 3): channel c of the image is written as hi = fp16(v) at
- * dst_choff + c, lo = fp16(v - hi) at dst_choff + plane + c and hi again at dst_choff + 2 * plane + c -- the network
- * input of the "fp16x3" / "mixed" precision modes (nets.py:720 takes the image as fp32 NCHW). */
 /* As mcamd_nchw_f32_to_padded_nhwc_f16 with the destination in the shared-halo form when pad == 1. */
 int mcamd_nchw_f32_to_padded_nhwc_f16_pad(const float* src, int32_t B, int32_t C, int32_t H, int32_t W,
                                           float mul, void* dst, int32_t dst_ld, int32_t dst_choff, int32_t pad,
                                           int32_t* overflow, void* stream);
+/* The same into split storage (mcamd_act_desc.planes == 3): channel c of the image is written as hi = fp16(v) at
+ * dst_choff + c, lo = fp16(v - hi) at dst_choff + plane + c and hi again at dst_choff + 2 * plane + c -- the network
+ * input of the "fp16x3" / "mixed" precision modes (nets.py:720 takes the image as fp32 NCHW). */
 int mcamd_nchw_f32_to_padded_nhwc_f16_split(const float* src, int32_t B, int32_t C, int32_t H, int32_t W,
                                             void* dst, int32_t dst_ld, int32_t dst_choff, int32_t plane, void* stream);
+
+/* The first convolution of the split-operand precisions in fp32 on the vector ALUs, straight from the image
+ * (F.conv2d(x, weight * mask, None, 1, 1) at layers.py:60-64 for a 3-channel input, 3x3 kernel, 32 filters):
+ *   x_nchw fp32 [B][3][H][W] -> y fp32 [B*H*W][y_ld] (channels 0..31), exact fp32 products and sums;
+ *   stats (may be NULL): fp32 [stats_rows][2][stats_ld] partial sums / sums of squares of y per filter, one row per
+ *   workgroup, stats_rows == mcamd_stem_conv_f32_stats_rows(); mcamd_bn_coeffs adds the rows (training mode);
+ *   weff_scratch: 32 * 27 floats of device memory the call may overwrite (weight * mask).
+ * Other filter counts are refused (the caller then multiplies split operands through mcamd_conv_fwd). */
+int32_t mcamd_stem_conv_f32_stats_rows(void);
+int mcamd_stem_conv_f32(const float* x_nchw, int32_t B, int32_t H, int32_t W, const float* w_oihw,
+                        const float* mask_oihw, int32_t cout, float* weff_scratch, float* y, int32_t y_ld,
+                        float* stats, int32_t stats_rows, int32_t stats_ld, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Region loss of the training step (reference src/nets.py:282-635: build_targets + RegionLoss.forward, called at

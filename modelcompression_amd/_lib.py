@@ -46,7 +46,7 @@ class PackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("mask", C.c_void_p), ("dst_fwd", C.c_void_p), ("dst_dgrad", C.c_void_p),
                 ("rows", C.c_void_p), ("cols", C.c_void_p),
                 ("first_tile", C.c_int64), ("cout", C.c_int32), ("cin", C.c_int32), ("ksize", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("split", C.c_int32)]
 
 
 class ActBwdDesc(C.Structure):
@@ -128,6 +128,8 @@ SIGNATURES = {
     "mcamd_nchw_f32_to_padded_nhwc_f16": (C.c_int, [_P, _I32, _I32, _I32, _I32, _F, _P, _I32, _I32, _P, _P]),
     "mcamd_nchw_f32_to_padded_nhwc_f16_pad": (C.c_int, [_P, _I32, _I32, _I32, _I32, _F, _P, _I32, _I32, _I32, _P, _P]),
     "mcamd_nchw_f32_to_padded_nhwc_f16_split": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _P]),
+    "mcamd_stem_conv_f32_stats_rows": (_I32, []),
+    "mcamd_stem_conv_f32": (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _I32, _P, _I32, _I32, _P]),
     "mcamd_region_loss_workspace_bytes": (_SZ, [_I32]),
     "mcamd_region_loss": (C.c_int, [C.POINTER(RegionDesc), _P, _P, _P, _P, _SZ, _P]),
     "mcamd_plan_begin": (C.c_int, [C.POINTER(_P), _I32]),

@@ -23,6 +23,7 @@ SOURCES = {
     "conv_igemm_pp.hip": [],
     "conv_stem.hip": [],
     "conv_stem_block.hip": [],
+    "conv_stem_f32.hip": [],
     "conv_small.hip": [],
     "conv_win.hip": [],
     "conv_wres.hip": [],

@@ -256,23 +256,34 @@ __global__ __launch_bounds__(256) void pack_tiles_kernel(const mcamd_pack_job* j
             }
         }
         __syncthreads();
-        // 2. forward layout [n][kpos(t, c)]: 8 consecutive channels of one (filter, tap) per lane = one 16-byte store
+        // 2. forward layout [n][kpos(t, c)]: 8 consecutive channels of one (filter, tap) per lane = one 16-byte store.
+        // j.split: the split-operand packing [w_hi | w_hi | w_lo] along the input channels (w_hi = fp16(w * mask),
+        // w_lo = fp16(w * mask - w_hi)), i.e. channel c is written at c, cin + c and 2 cin + c of a 3 cin wide row.
         if (j.dst_fwd) {
             half_t* dst = (half_t*)j.dst_fwd;
-            const int cin_tap = round_up_dev(j.cin, 32);
+            const int parts = j.split ? 3 : 1;
+            const int cin_tap = round_up_dev(j.cin * parts, 32);
+            const bool vec_ok = parts == 1 || j.cin % 8 == 0;
             for (int e = threadIdx.x; e < TS * kk * (TS / 8); e += 256) {
                 const int g8 = e % (TS / 8), t = (e / (TS / 8)) % kk, nl = e / ((TS / 8) * kk);
                 const int n = n0 + nl, c = c0 + g8 * 8;
                 if (n >= j.cout || c >= j.cin) continue;
-                half_t* d = dst + (long long)n * kk * cin_tap + kpos(t, c, kk, cin_tap);
                 const float* src = tile + nl * LDW + (g8 * 8) * kk + t;
-                if (c + 8 <= j.cin) {
+                const int lim = c + 8 <= j.cin ? 8 : j.cin - c;
+                for (int part = 0; part < parts; ++part) {
+                    half_t* d = dst + (long long)n * kk * cin_tap + kpos(t, c + part * j.cin, kk, cin_tap);
                     h8_t h;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) h[i] = (half_t)src[i * kk];
-                    *(h8_t*)d = h;
-                } else {
-                    for (int i = 0; c + i < j.cin; ++i) d[i] = (half_t)src[i * kk];
+                    for (int i = 0; i < 8; ++i) {
+                        const float v = i < lim ? src[i * kk] : 0.f;
+                        const half_t hi = (half_t)v;
+                        h[i] = part < 2 ? hi : (half_t)(v - (float)hi);
+                    }
+                    if (lim == 8 && vec_ok) {
+                        *(h8_t*)d = h;
+                    } else {
+                        for (int i = 0; i < lim; ++i) dst[(long long)n * kk * cin_tap + kpos(t, c + i + part * j.cin, kk, cin_tap)] = h[i];
+                    }
                 }
             }
         }

@@ -416,6 +416,7 @@ class Engine:
             lay.dy = None if (lay.fused_stem or lay.stem_shadow) else ops.alloc_padded(B, lay.H, lay.W, lay.cout_p, dev, pad=lay.pad)
             lay.keep, lay.keep_key = None, None
             lay.gin = None
+            lay.stem_f32 = False
             if lay.li > 0:
                 lay.gin = torch.empty(lay.M * lay.tin.ld, dtype=ops.HALF, device=dev)
             lay.perm = lay.perm32 = lay.in_perm = lay.g_rows = lay.g_cols = None
@@ -425,10 +426,19 @@ class Engine:
                     lay.y = lay.stats = None
                     lay.stem_ws = torch.empty(ops.stem_block_workspace_bytes(), dtype=torch.uint8, device=dev)
                 else:
+                    # The first convolution of the split-operand modes: fp32 on the vector ALUs straight from the fp32 image
+                    # (csrc/conv_stem_f32.hip) instead of hi | lo | hi image planes through the generic MFMA kernel
+                    # (layout 0.38 + conv 0.86 ms per B=64 step -> 0.4 ms, and exact fp32 products).
+                    lay.stem_f32 = bool(self.precise and li_is_first(lay) and lay.cin == 3 and lay.k == 3 and lay.cout == 32
+                                        and lay.bn is not None and os.environ.get("MCAMD_STEM_F32", "1") == "1")
                     # zero-initialised: with filter compaction the convolution writes the kept channels only
                     lay.y = torch.zeros(lay.M * lay.cout, dtype=torch.float32 if self.precise else ops.HALF, device=dev)
-                    lay.stats = torch.zeros(ops.stats_rows(lay.geom_f, L.EPI_RAW_F32 if self.precise else L.EPI_RAW_F16), 2,
-                                            ops.round_up(lay.cout, 256), **f32)
+                    if lay.stem_f32:
+                        lay.stats = torch.zeros(ops.stem_conv_f32_stats_rows(), 2, ops.round_up(lay.cout, 256), **f32)
+                        lay.weff = torch.empty(lay.cout * 27, **f32)
+                    else:
+                        lay.stats = torch.zeros(ops.stats_rows(lay.geom_f, L.EPI_RAW_F32 if self.precise else L.EPI_RAW_F16), 2,
+                                                ops.round_up(lay.cout, 256), **f32)
                 lay.scale, lay.shift, lay.mean, lay.invstd = (torch.empty(lay.cout, **f32) for _ in range(4))
                 lay.out_t = place.get(lay.out_id)
                 lay.out2_t = place.get(lay.out2_id) if lay.out2_id is not None else None
@@ -610,23 +620,34 @@ class Engine:
     def _pack_split(self):
         """Packings of the split-operand modes: forward = fp16 of [w_hi | w_hi | w_lo] along the input channels
         (w_hi = fp16(w * mask), w_lo = fp16(w * mask - w_hi)), matching the [x_hi | x_lo | x_hi] activation planes;
-        dgrad = the plain fp16 packing (the backward pass multiplies plain operands)."""
+        dgrad = the plain fp16 packing (the backward pass multiplies plain operands).  One launch for all layers: the
+        packer splits the master itself (mcamd_pack_job.split; round 3 formed the three parts with torch ops per layer,
+        ~1.2 ms of small kernels per step)."""
+        key = tuple((lay.conv.weight.data_ptr(), lay.conv.mask.data_ptr() if lay.conv.mask_flag else 0) for lay in self.layers)
+        if key != self._pack_key:
+            jobs, self._pack_keep = [], []
+            for lay in self.layers:
+                w = lay.conv.weight.data
+                if w.dtype != torch.float32 or not w.is_contiguous():
+                    raise McamdError("conv weights must be contiguous fp32 (master copy)")
+                mask = lay.conv.mask if lay.conv.mask_flag else None
+                if mask is not None and not mask.is_contiguous():
+                    raise McamdError("conv masks must be contiguous")
+                if lay.stem:
+                    continue
+                self._pack_keep += [w, mask]
+                jobs.append(dict(w=w, mask=mask, rows=None, cols=None, cout=lay.cout, cin=lay.cin, ksize=lay.k,
+                                 dst_fwd=lay.wp, dst_dgrad=lay.wd, split=lay.level == 3))
+            self._pack_table = ops.pack_table(jobs, self.device) if jobs else None
+            self._pack_key = key
+        if self._pack_table is not None:
+            ops.pack_many(*self._pack_table)
         for lay in self.layers:
-            w = lay.conv.weight.data
-            if w.dtype != torch.float32 or not w.is_contiguous():
-                raise McamdError("conv weights must be contiguous fp32 (master copy)")
-            mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
-            if lay.level == 1:
-                ops.pack_weights(lay.geom_f, w, mask, True, False, lay.wp, None)
-            else:
-                weff = w * mask if mask is not None else w
-                hi = weff.half().float()
-                parts = [hi, hi, weff - hi][:lay.level]
-                ops.pack_weights(lay.geom_f, torch.cat(parts, 1).contiguous(), None, True, False, lay.wp, None)
-            if lay.wd is not None:
-                ops.pack_weights(lay.geom, w, mask, False, True, None, lay.wd)
+            mask = lay.conv.mask if lay.conv.mask_flag else None
+            if lay.stem:
+                ops.pack_weights(lay.geom_f, lay.conv.weight.data, mask, True, False, lay.wp, None)
             if getattr(lay, "stem_shadow", False):
-                ops.pack_weights(lay.sh_geom, w, mask, True, False, lay.sh_wp, None)
+                ops.pack_weights(lay.sh_geom, lay.conv.weight.data, mask, True, False, lay.sh_wp, None)
 
     # ------------------------------------------------------------------ filter compaction
     def _update_compaction(self):
@@ -808,12 +829,23 @@ class Engine:
         self.serial += 1
         tin = self.layers[0].tin
         xs = x.detach().contiguous().float()
-        if self.precise and not self.stem:        # the image too is an MFMA operand: hi | lo | hi planes
-            # (written by the layout kernel itself: round 2 built the planes with torch.cat, three 3 x B x H x W fp32
-            # temporaries per forward -- 0.8 GB at B=128 through the caching allocator)
-            ops.nchw_to_padded_split(xs, self.bufs[tin.buf], tin.ld, tin.choff, tin.ps)
-            if training and self.layers[0].stem_shadow:
-                ops.nchw_to_padded(xs, self.layers[0].sh_img, 4, 0)
+        if self.precise and not self.stem:
+            l0 = self.layers[0]
+            if l0.stem_f32:
+                # the first convolution in fp32 from the image itself (outside the recorded plan: the image pointer is
+                # the caller's); the hi plane of the image is still needed where the generic weight gradient reads it
+                if training and not l0.stem_shadow:
+                    ops.nchw_to_padded_split(xs, self.bufs[tin.buf], tin.ld, tin.choff, tin.ps)
+                mask0 = l0.conv.mask if l0.conv.mask_flag else None
+                self._timed('fwd', l0, ops.stem_conv_f32, xs, l0.conv.weight.data, mask0, l0.weff, l0.y, l0.cout,
+                            l0.stats if training else None)
+            else:
+                # the image too is an MFMA operand: hi | lo | hi planes
+                # (written by the layout kernel itself: round 2 built the planes with torch.cat, three 3 x B x H x W fp32
+                # temporaries per forward -- 0.8 GB at B=128 through the caching allocator)
+                ops.nchw_to_padded_split(xs, self.bufs[tin.buf], tin.ld, tin.choff, tin.ps)
+            if training and l0.stem_shadow:
+                ops.nchw_to_padded(xs, l0.sh_img, 4, 0)
         else:
             ops.nchw_to_padded(xs, self.bufs[tin.buf], tin.ld, tin.choff)
         if self._logits is None:
@@ -878,8 +910,9 @@ class Engine:
             if self.precise:
                 # unrounded fp32 raw output (+ batch statistics from the fp32 values), then BN + LeakyReLU
                 # (+ pool / reorg / route) written as hi | lo | hi planes
-                self._timed('fwd', lay, ops.conv_fwd_raw32, lay.geom_f, xin, lay.wp, lay.y, lay.cout, 0,
-                            lay.stats if training else None)
+                if not lay.stem_f32:        # (the fp32 first convolution ran in forward(), from the caller's image)
+                    self._timed('fwd', lay, ops.conv_fwd_raw32, lay.geom_f, xin, lay.wp, lay.y, lay.cout, 0,
+                                lay.stats if training else None)
                 ops.bn_coeffs(lay.stats if training else None, lay.cout, lay.M, bn.weight.data, bn.bias.data,
                               bn.running_mean, bn.running_var, training, lay.scale, lay.shift, lay.mean, lay.invstd,
                               momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps)

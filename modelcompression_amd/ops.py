@@ -104,7 +104,7 @@ def pack_weights(g, w, mask=None, want_fwd=True, want_dgrad=True, out_fwd=None, 
 
 
 def pack_table(jobs, device):
-    """jobs: list of dicts(w, mask, dst_fwd, dst_dgrad, rows, cols, cout, cin, ksize), one per layer ->
+    """jobs: list of dicts(w, mask, dst_fwd, dst_dgrad, rows, cols, cout, cin, ksize[, split]), one per layer ->
     (device table, njobs, total tiles) for `pack_many` (mcamd_pack_job array).  The tensors must stay alive and
     in place while the table is used."""
     arr = (PackJob * len(jobs))()
@@ -116,6 +116,7 @@ def pack_table(jobs, device):
         for name in ("mask", "dst_fwd", "dst_dgrad", "rows", "cols"):
             setattr(a, name, j[name].data_ptr() if j.get(name) is not None else None)
         a.first_tile, a.cout, a.cin, a.ksize = total, j["cout"], j["cin"], j["ksize"]
+        a.split = 1 if j.get("split") else 0
         total += ((j["cout"] + 31) // 32) * ((j["cin"] + 31) // 32)
     host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
     return host.to(device), len(jobs), total
@@ -405,6 +406,25 @@ def nchw_to_padded_split(src, dst, dst_ld, dst_choff, plane):
     B, C_, H, W = src.shape
     check(L.lib().mcamd_nchw_f32_to_padded_nhwc_f16_split(ptr(src), B, C_, H, W, ptr(dst), dst_ld, dst_choff, plane,
                                                           stream_ptr()), "mcamd_nchw_f32_to_padded_nhwc_f16_split")
+
+
+def stem_conv_f32_stats_rows():
+    return int(L.lib().mcamd_stem_conv_f32_stats_rows())
+
+
+def stem_conv_f32(x, w, mask, weff_scratch, y, y_ld, stats=None):
+    """The first convolution (3 -> 32 channels, 3x3, pad 1) in fp32 from the fp32 NCHW image: y fp32 [B*H*W][y_ld];
+    `stats` fp32 [stem_conv_f32_stats_rows()][2][ld] receives the per-workgroup sums for mcamd_bn_coeffs."""
+    _need_cuda(x, w, mask, weff_scratch, y, stats)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and x.shape[1] == 3
+    assert w.dtype == torch.float32 and w.is_contiguous() and tuple(w.shape[1:]) == (3, 3, 3)
+    assert mask is None or (mask.dtype == torch.float32 and mask.is_contiguous() and mask.shape == w.shape)
+    assert weff_scratch.dtype == torch.float32 and weff_scratch.numel() >= w.numel() and y.dtype == torch.float32
+    B, _, H, W = x.shape
+    assert y.numel() >= B * H * W * y_ld
+    srows, sld = (stats.shape[0], stats.shape[2]) if stats is not None else (0, 0)
+    check(L.lib().mcamd_stem_conv_f32(ptr(x), B, H, W, ptr(w), ptr(mask), w.shape[0], ptr(weff_scratch), ptr(y), y_ld, ptr(stats),
+                                      srows, sld, stream_ptr()), "mcamd_stem_conv_f32")
 
 
 def region_loss(output, target, anchors, num_anchors, num_classes, coord_scale, noobject_scale, object_scale, class_scale, thresh,

@@ -317,6 +317,63 @@ def test_pack_many_equals_per_layer_pack(dev):
     assert torch.equal(only, want[0])
 
 
+@pytest.mark.parametrize("B,H,W,masked", [(2, 24, 40, False), (3, 33, 17, True), (1, 416, 416, True)])
+def test_stem_conv_f32(dev, B, H, W, masked):
+    """mcamd_stem_conv_f32 (the first convolution of the split-operand precisions, fp32 on the vector ALUs) against
+    F.conv2d in float64: fp32 rounding only (bar 2e-6), zero padding at every border, and the per-workgroup partial
+    sums add up to the sums of y and y * y."""
+    gen = torch.Generator().manual_seed(B * 1000 + H)
+    x = torch.rand(B, 3, H, W, generator=gen)
+    w = torch.randn(32, 3, 3, 3, generator=gen) * 0.3
+    mask = (torch.rand(32, 3, 3, 3, generator=gen) > 0.3).float() if masked else None
+    weff = w * mask if masked else w
+    ref = F.conv2d(x.double(), weff.double(), None, 1, 1)
+    y = torch.full((B * H * W * 32,), float("nan"), device=dev)
+    stats = torch.full((ops.stem_conv_f32_stats_rows(), 2, 256), float("nan"), device=dev)
+    scratch = torch.empty(32 * 27, device=dev)
+    ops.stem_conv_f32(x.to(dev), w.to(dev), mask.to(dev) if masked else None, scratch, y, 32, stats)
+    got = y.view(B, H, W, 32).permute(0, 3, 1, 2).cpu()
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, ref) < 2e-6
+    assert float((got.double() - ref).abs().max()) < 1e-5
+    s = stats[:, :, :32].double().sum(0).cpu()
+    assert torch.allclose(s[0], ref.sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s[1], (ref * ref).sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+    # without statistics (eval) the output is the same
+    y2 = torch.empty_like(y)
+    ops.stem_conv_f32(x.to(dev), w.to(dev), mask.to(dev) if masked else None, scratch, y2, 32, None)
+    assert torch.equal(y, y2)
+    with pytest.raises(L.McamdError):
+        ops.stem_conv_f32(x.to(dev), torch.zeros(16, 3, 3, 3, device=dev), None, scratch, y2, 32, None)
+
+
+def test_pack_many_split_operands(dev):
+    """mcamd_pack_job.split: the one-launch packer writes the [w_hi | w_hi | w_lo] forward packing of the split-operand
+    precisions bit for bit as the per-layer packing of torch.cat([hi, hi, w * mask - hi], 1) does (what the engine
+    built with torch ops before), and the plain dgrad packing next to it."""
+    gen = torch.Generator().manual_seed(43)
+    cases = [(3, 64, 128, False), (1, 256, 64, True), (3, 32, 64, True), (3, 3, 32, True), (1, 1280, 40, False)]
+    jobs, want, keep = [], [], []
+    for k, cin, cout, masked in cases:
+        w = (torch.randn(cout, cin, k, k, generator=gen) * 0.1).to(dev).contiguous()
+        mask = (torch.rand(cout, cin, k, k, generator=gen) > 0.3).float().to(dev).contiguous() if masked else None
+        weff = w * mask if mask is not None else w
+        hi = weff.half().float()
+        g3 = ops.geom(2, 8, 8, k, 3 * cin, cout, ops.round_up(3 * cin, 32))
+        g1 = ops.geom(2, 8, 8, k, cin, cout, ops.round_up(cin, 32))
+        wp, _ = ops.pack_weights(g3, torch.cat([hi, hi, weff - hi], 1).contiguous(), None, True, False)
+        _, wd = ops.pack_weights(g1, w, mask, False, True)
+        want += [wp, wd]
+        mine = [torch.zeros_like(wp), torch.zeros_like(wd)]
+        keep += [w, mask] + mine
+        jobs.append(dict(w=w, mask=mask, rows=None, cols=None, cout=cout, cin=cin, ksize=k, dst_fwd=mine[0], dst_dgrad=mine[1],
+                         split=True))
+    ops.pack_many(*ops.pack_table(jobs, dev))
+    for idx, j in enumerate(jobs):
+        assert torch.equal(j["dst_fwd"], want[2 * idx]), (j["cout"], j["cin"], j["ksize"], "split fwd")
+        assert torch.equal(j["dst_dgrad"], want[2 * idx + 1]), (j["cout"], j["cin"], j["ksize"], "dgrad")
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 24, 40), (2, 40, 64), (3, 33, 96)])   # generic kernel | raw-window kernel (W % 32 == 0)
 def test_wgrad_stem(dev, B, H, W):
     cout = 32
