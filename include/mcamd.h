@@ -111,6 +111,10 @@ typedef struct mcamd_conv_epilogue {
                                   route that reads the block beside its pool: conv13 of yolov2-voc.cfg) */
     int32_t y2_ld, y2_choff;
     /* (mode 2 writes the standard padded form: inference engines do not use the shared-halo one) */
+    int32_t concurrent;        /* mcamd_conv_dgrad only, 0 / 1: the caller runs other kernels on another stream at the
+                                  same time (the training engine: the weight gradients of the layers behind).  The launch
+                                  then picks the workgroup tile with the least CU-time even if it fills only 40-80 % of the
+                                  CUs, instead of the tile with the shortest launch on an otherwise idle GPU. */
 } mcamd_conv_epilogue;
 
 /* Rows of the BatchNorm partial-sum slab a forward launch of this geometry writes (epilogue mode 0). */
@@ -119,7 +123,8 @@ int32_t mcamd_conv_stats_rows(const mcamd_conv_geom* g);
  * the LDS-staged implicit-GEMM kernels, so the slab shape differs for the layers that otherwise take a streaming kernel). */
 int32_t mcamd_conv_stats_rows_mode(const mcamd_conv_geom* g, int32_t mode);
 
-/* Workgroup tile {BM, BN, BK, kernel} the forward (dgrad == 0) or dgrad launch of this geometry uses:
+/* Workgroup tile {BM, BN, BK, kernel} the forward (dgrad == 0) or dgrad launch (1; 2 = with epilogue.concurrent set) of
+ * this geometry uses:
  * kernel 0 = igemm_kernel<BM,BN,..,BK,..> (one tap per K chunk),
  * 2 = igemm_pp_kernel (ping-pong, one workgroup per CU), 1 = stem_fwd_kernel (first layer, no LDS staging),
  * 4 = small3x3_kernel (narrow 3x3 layers on huge images, no LDS staging), 5 = win3x3_kernel (rolling LDS window),

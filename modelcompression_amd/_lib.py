@@ -25,7 +25,8 @@ class ConvEpilogue(C.Structure):
                 ("y", C.c_void_p), ("bias", C.c_void_p), ("stats", C.c_void_p),
                 ("stats_rows", C.c_int32), ("stats_ld", C.c_int32),
                 ("scale", C.c_void_p), ("shift", C.c_void_p), ("slope", C.c_float), ("overflow", C.c_void_p),
-                ("dst_mode", C.c_int32), ("y2", C.c_void_p), ("y2_ld", C.c_int32), ("y2_choff", C.c_int32)]
+                ("dst_mode", C.c_int32), ("y2", C.c_void_p), ("y2_ld", C.c_int32), ("y2_choff", C.c_int32),
+                ("concurrent", C.c_int32)]
 
 
 class ActDesc(C.Structure):

@@ -426,7 +426,8 @@ extern "C" int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int
         return MCAMD_OK;
     }
     mcamd_igemm_tile((long long)g->B * g->H * g->W, dgrad ? g->cin : g->cout, dgrad ? cout_p_of(g) : cin_tap_of(g),
-                     dgrad ? g->ksize * g->ksize * cout_p_of(g) : ntaps_of(g) * cin_tap_of(g), out);
+                     dgrad ? g->ksize * g->ksize * cout_p_of(g) : ntaps_of(g) * cin_tap_of(g), out,
+                     dgrad == 2 && MCAMD_ENV_INT("MCAMD_CONCURRENT_TILES", 1) != 0);
     return MCAMD_OK;
 }
 
@@ -506,6 +507,7 @@ extern "C" int mcamd_conv_dgrad(const mcamd_conv_geom* g, const void* dy, int32_
     MCAMD_REQUIRE(epi && epi->mode != MCAMD_EPI_PAD_F16 && !epi->stats && epi->dst_mode == 0 && !epi->y2,
                   "conv_dgrad: epilogue must be mode 0 (no stats) or 1");
     if (fill_epilogue(a, epi, g->cin, a.M, a.cin_tap, a.ktot, "conv_dgrad")) return MCAMD_EINVAL;
+    a.concurrent = epi->concurrent != 0;
     return mcamd_igemm_launch(a, (hipStream_t)stream);
 }
 

@@ -347,7 +347,7 @@ struct TileCfg {
 // the kernel (bytes per flop = (1/BM + 1/BN) / 1), so bigger tiles are faster per tile, but the
 // machine has 256 CUs and the late layers have few tiles: pick the candidate with the best
 // (rate of the tile shape) x (fill of the last round of workgroups).
-static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot, bool raw_epilogue = true) {
+static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot, bool raw_epilogue = true, bool concurrent = false) {
     TileCfg t;
     t.kind = 0;
     if (raw_epilogue && mcamd_small3x3_ok(M, n, cin_tap, ktot)) {   // narrow 3x3 layers on huge images: no LDS staging at all
@@ -372,16 +372,28 @@ static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot, bool raw_epi
                 // it runs ONE workgroup per CU, so it only pays when its tiles fill the 256 CUs well: 256 or 192 rows,
                 // 256 or 128 columns (128 columns stage 1.3x the bytes per flop: costed at 0.8 of the 256-column rate),
                 // whichever fills >= 80 % with the smallest estimated time.
-                double best_cost = -1.0;
+                //
+                // `concurrent` (input gradients of the training step: the weight gradients of the layers behind run on a
+                // second stream at the same time and take whatever CUs this launch leaves idle): the candidates also include
+                // tiles that fill only 40-80 % of ONE round, and the cost is the CU-time (tiles x tile / rate), not the
+                // makespan.  The 13x13 input gradients with 512 columns then take the 192x256 tile on 114 CUs instead of
+                // 192x128 on 228 (alone: 0.135 -> ~0.2 ms per launch; in the step: 9.234 -> 9.137 ms, A/B on one box).
+                double best_cost = -1.0, best_span = 0.0;
                 const int bms[2] = {256, 192}, bns[2] = {256, 128};
                 for (int cn = 0; cn < 2; ++cn) {
                     if (n < bns[cn]) continue;
                     for (int c = 0; c < 2; ++c) {
                         const long long tiles = ((M + bms[c] - 1) / bms[c]) * ((n + bns[cn] - 1) / bns[cn]);
                         const long long rounds = (tiles + 255) / 256;
-                        if ((double)tiles / (double)(rounds * 256) < 0.8) continue;
-                        const double cost = (double)rounds * bms[c] * bns[cn] / (bns[cn] == 256 ? 1.0 : 0.8);
-                        if (best_cost < 0 || cost < best_cost) best_cost = cost, bm = bms[c], bn = bns[cn];
+                        const double fill = (double)tiles / (double)(rounds * 256);
+                        const double rate = bns[cn] == 256 ? 1.0 : 0.8;
+                        if (fill < 0.8 && !(concurrent && rounds == 1 && fill >= 0.4)) continue;
+                        const double span = (double)rounds * bms[c] * bns[cn] / rate;
+                        const double cost = concurrent ? (double)tiles * bms[c] * bns[cn] / rate : span;
+                        // (concurrent: CU-times within 3 % count as equal and the shorter launch wins)
+                        const bool better = best_cost < 0 || (concurrent ? (cost < 0.97 * best_cost || (cost < 1.03 * best_cost && span < best_span))
+                                                                         : cost < best_cost);
+                        if (better) best_cost = cost, best_span = span, bm = bms[c], bn = bns[cn];
                     }
                 }
                 use = best_cost >= 0;
@@ -427,16 +439,16 @@ static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot, bool raw_epi
     return t;
 }
 
-void mcamd_igemm_tile(long long M, int n, int cin_tap, int ktot, int out[4]) {
-    TileCfg t = pick_tile(M, n, cin_tap, ktot);
+void mcamd_igemm_tile(long long M, int n, int cin_tap, int ktot, int out[4], bool concurrent) {
+    TileCfg t = pick_tile(M, n, cin_tap, ktot, true, concurrent);
     out[0] = t.bm, out[1] = t.bn, out[2] = t.bk, out[3] = t.kind;
 }
 
 static int igemm_mtiles(long long M, int bm) { return (int)((M + bm - 1) / bm); }
 
 // Number of persistent workgroups along M (== rows of the BN-statistics slab).
-int mcamd_igemm_rows(long long M, int n, int cin_tap, int ktot, bool raw_epilogue) {
-    TileCfg t = pick_tile(M, n, cin_tap, ktot, raw_epilogue);
+int mcamd_igemm_rows(long long M, int n, int cin_tap, int ktot, bool raw_epilogue, bool concurrent) {
+    TileCfg t = pick_tile(M, n, cin_tap, ktot, raw_epilogue, concurrent);
     int ntiles = (n + t.bn - 1) / t.bn;
     int mtiles = igemm_mtiles(M, t.bm);
     if (t.kind == 4) return mcamd_small3x3_rows(M);
@@ -469,7 +481,8 @@ static void launch_one(const IgemmArgs& a, int rows, int ntiles, hipStream_t st)
 // a.* geometry fields must be filled by the caller; picks the tile and launches.
 int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st) {
     if (mcamd_win3x3_ok(a)) return mcamd_win3x3_launch(a, st);   // conv2 dgrad: rolling LDS window (conv_win.hip)
-    TileCfg t = pick_tile(a.M, a.N, a.cin_tap, a.ktot, a.mode == MCAMD_EPI_RAW_F16);   // stats slabs only exist with RAW
+    const bool conc = a.concurrent != 0 && MCAMD_ENV_INT("MCAMD_CONCURRENT_TILES", 1) != 0;
+    TileCfg t = pick_tile(a.M, a.N, a.cin_tap, a.ktot, a.mode == MCAMD_EPI_RAW_F16, conc);   // stats slabs only exist with RAW
     if (t.kind == 4) return mcamd_small3x3_launch(a, st);
     if (a.cin_tap % t.bk != 0 || a.ktot % t.bk != 0) {
         mcamd_set_error("igemm: K per tap (%d) must be a multiple of %d", a.cin_tap, t.bk);
@@ -477,7 +490,7 @@ int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st) {
     }
     int ntiles = (a.N + t.bn - 1) / t.bn;
     a.num_mtiles = igemm_mtiles(a.M, t.bm);
-    int rows = mcamd_igemm_rows(a.M, a.N, a.cin_tap, a.ktot, a.mode == MCAMD_EPI_RAW_F16);
+    int rows = mcamd_igemm_rows(a.M, a.N, a.cin_tap, a.ktot, a.mode == MCAMD_EPI_RAW_F16, conc);
     a.num_pslots = rows;
     a.num_ntiles = ntiles;
     a.xcd_order = MCAMD_ENV_INT("MCAMD_XCD_ORDER", 1);

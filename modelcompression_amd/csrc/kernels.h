@@ -34,6 +34,7 @@ struct IgemmArgs {
     int dst_mode;
     void* y2;
     int y2_ld, y2_choff;
+    int concurrent;  // mcamd_conv_epilogue.concurrent (dgrad): tiles chosen for CU-time, see pick_tile
 };
 
 struct StemArgs {        // conv_stem.hip: forward of the 3-channel first layer
@@ -70,9 +71,9 @@ struct WgradPlan {
     size_t bytes;
 };
 
-void mcamd_igemm_tile(long long M, int n, int cin_tap, int ktot, int out[4]);   // {BM, BN, BK, kind}: kind 0 igemm_kernel, 2 igemm_pp_kernel
+void mcamd_igemm_tile(long long M, int n, int cin_tap, int ktot, int out[4], bool concurrent = false);   // {BM, BN, BK, kind}: kind 0 igemm_kernel, 2 igemm_pp_kernel
 int mcamd_igemm_pp_launch(const IgemmArgs& a, int bm, int bn, int rows, int ntiles, hipStream_t st);
-int mcamd_igemm_rows(long long M, int n, int cin_tap, int ktot, bool raw_epilogue = true);
+int mcamd_igemm_rows(long long M, int n, int cin_tap, int ktot, bool raw_epilogue = true, bool concurrent = false);
 int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st);
 
 WgradPlan mcamd_wgrad_plan(long long M, int cout, int cin_tap, int ntaps);

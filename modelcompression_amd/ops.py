@@ -128,9 +128,9 @@ def pack_many(table, njobs, total):
     check(L.lib().mcamd_pack_weights_many(ptr(table), njobs, total, stream_ptr()), "mcamd_pack_weights_many")
 
 
-def tile_info(g, dgrad=False):
+def tile_info(g, dgrad=False, concurrent=False):
     out = (C.c_int32 * 4)()
-    check(L.lib().mcamd_conv_tile_info(C.byref(g), 1 if dgrad else 0, out), "mcamd_conv_tile_info")
+    check(L.lib().mcamd_conv_tile_info(C.byref(g), (2 if concurrent else 1) if dgrad else 0, out), "mcamd_conv_tile_info")
     return tuple(out)
 
 
@@ -187,9 +187,11 @@ def conv_fwd_padded(g, x, wp, y, y_ld, y_choff=0, scale=None, shift=None, slope=
     check(L.lib().mcamd_conv_fwd(C.byref(g), ptr(x), ptr(wp), C.byref(e), stream_ptr()), "mcamd_conv_fwd")
 
 
-def conv_dgrad_raw(g, dy, dy_ld, dy_choff, wpd, out, out_ld, out_choff=0, overflow=None):
-    """`overflow`: optional int32[1] device flag, set when a (scaled) gradient was clamped to the fp16 range."""
+def conv_dgrad_raw(g, dy, dy_ld, dy_choff, wpd, out, out_ld, out_choff=0, overflow=None, concurrent=False):
+    """`overflow`: optional int32[1] device flag, set when a (scaled) gradient was clamped to the fp16 range.
+    `concurrent`: another stream has work for the CUs this launch leaves idle (mcamd_conv_epilogue.concurrent)."""
     e = _epi(L.EPI_RAW_F16, out, out_ld, out_choff, overflow=overflow)
+    e.concurrent = 1 if concurrent else 0
     check(L.lib().mcamd_conv_dgrad(C.byref(g), ptr(dy), dy_ld, dy_choff, ptr(wpd), C.byref(e), stream_ptr()),
           "mcamd_conv_dgrad")
 
