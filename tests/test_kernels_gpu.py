@@ -234,6 +234,32 @@ def test_channel_maps_pack_fwd_dgrad_wgrad(dev, k, cin, cout_full, n_phys):
     assert rel_l2(y2.cpu(), F.conv2d(q16(x_phys), q16(w[rows]), None, 1, (k - 1) // 2)) < TOL
 
 
+@pytest.mark.parametrize("B", [64, 32])
+def test_dgrad_concurrent_tile_choice(dev, B):
+    """mcamd_conv_epilogue.concurrent (the training engine's input gradients, which run beside the weight-gradient
+    stream): the 13x13 layers with 512 input channels take the 256-column ping-pong tile on under half of the CUs
+    (B=64: 192x256 instead of 192x128; B=32: a ping-pong tile instead of the 64-column fill tile) -- and the result is
+    bit for bit the one of the default tile (same accumulation order over K)."""
+    H = W = 13
+    cin, cout, k = 512, 1024, 3
+    gen = torch.Generator().manual_seed(77)
+    gy = torch.randn(B, cout, H, W, generator=gen)
+    w = torch.randn(cout, cin, k, k, generator=gen) * (2.0 / (cin * k * k)) ** 0.5
+    dyb, dy_ld = to_padded(gy.to(dev))
+    g = ops.geom(B, H, W, k, cin, cout, cin)
+    _, wd = ops.pack_weights(g, w.to(dev).contiguous())
+    t_alone, t_conc = ops.tile_info(g, dgrad=True), ops.tile_info(g, dgrad=True, concurrent=True)
+    print("B=%d dgrad tile alone %s, concurrent %s" % (B, t_alone, t_conc))
+    assert t_conc[3] == 2 and t_conc != t_alone
+    assert t_conc[:2] == ((192, 256) if B == 64 else (192, 128))
+    out = [torch.zeros(B * H * W * cin, dtype=torch.float16, device=dev) for _ in range(2)]
+    ops.conv_dgrad_raw(g, dyb, dy_ld, 0, wd, out[0], cin)
+    ops.conv_dgrad_raw(g, dyb, dy_ld, 0, wd, out[1], cin, concurrent=True)
+    assert torch.equal(out[0], out[1])
+    wf = torch.flip(q16(w), (2, 3)).transpose(0, 1)
+    assert rel_l2(raw_to_nchw(out[1], B, H, W, cin, cin), F.conv2d(q16(gy), wf, None, 1, 1)) < TOL
+
+
 @pytest.mark.parametrize("B,H,W,cin,cout,k", [(4, 13, 13, 512, 1024, 3), (3, 26, 26, 256, 512, 3), (5, 20, 12, 1024, 256, 1),
                                               (4, 9, 11, 96, 320, 3)])
 def test_pingpong_igemm_vs_igemm(dev, setenv, B, H, W, cin, cout, k):
