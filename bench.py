@@ -504,7 +504,7 @@ def main():
     for (tag, li), (ms, n, lay) in sorted(per.items(), key=lambda kv: (kv[0][1], kv[0][0])):
         fl = eng.conv_flops(lay)
         avg = ms / n
-        tile = ops.tile_info(lay.geom_act, dgrad=(tag == "dgrad"), concurrent=eng.overlap_wgrad) if tag != "wgrad" else None
+        tile = ops.tile_info(lay.geom_act, dgrad=(tag == "dgrad")) if tag != "wgrad" else None   # (the instrumented pass runs every launch alone)
         tot[tag][0] += avg
         tot[tag][1] += fl
         rows.append("%-6s conv%-2d %4dx%-4d cin %4d cout %4d k%d  %8.3f ms  %8.1f TFLOP/s  tile %s" % (

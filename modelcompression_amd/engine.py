@@ -1152,10 +1152,10 @@ class Engine:
             if lay.li > 0:
                 # gradient wrt this block's input slice, written into gin at the slice's channel offset
                 # (concurrent: the weight gradients run beside this launch and take the CUs it leaves idle, so the library
-                # picks the tile with the least CU-time; also in the per-kernel timing mode, so that the layer table
-                # shows the kernels of the timed step)
+                # picks the tile with the least CU-time.  Not in the per-kernel timing mode, where every launch has the GPU
+                # to itself: the layer table then shows the tile that is fastest alone -- three launches differ)
                 self._timed('dgrad', lay, ops.conv_dgrad_raw, lay.geom_act, lay.dy, lay.cout_p, 0, lay.wd, lay.gin, lay.tin.ld,
-                            lay.tin.choff, overflow=self.overflow, concurrent=self.overlap_wgrad)
+                            lay.tin.choff, overflow=self.overflow, concurrent=self.overlap_wgrad and self.events is None)
         if side is not None:
             flush()
             ops.stream_wait(main, side)
