@@ -77,6 +77,12 @@ typedef struct mcamd_conv_geom {
     int32_t stem;         /* 1: first-layer form, x is NHWC4 (x_ld == 4), cin == 3, ksize == 3 */
     int32_t pad;          /* 0: padded NHWC; 1: shared-halo form (above) of EVERY padded operand of the call -- x in
                              mcamd_conv_fwd, dy in mcamd_conv_dgrad, x and dy in mcamd_conv_wgrad.  stem == 0 only. */
+    int32_t x_wrap;       /* mcamd_conv_fwd only, 0 = none.  Input channels >= x_wrap are read from channel - x_wrap of the
+                             pixel: the split-operand forward on TWO activation planes [x_hi | x_lo], plane stride P,
+                             with cin = 3 P, the K-concatenated weights [w_hi | w_hi | w_lo] (mcamd_pack_job.split) and
+                             x_wrap = 2 P: the third part multiplies the hi plane again without a third copy of it.
+                             P % 32 == 0; epilogue modes MCAMD_EPI_RAW_F32 / MCAMD_EPI_NCHW_F32; the buffer slice must hold
+                             x_wrap channels. */
 } mcamd_conv_geom;
 
 /* Output side of a convolution launch. */
@@ -252,8 +258,10 @@ typedef struct mcamd_act_desc {
                                   in fp32 on the fp16 MFMA path: operand rounding drops from 2^-11 to ~2^-21, which
                                   is what the reference's fp32 F.conv2d (layers.py:60-64) needs over 23 layers for
                                   1e-3 logits (tools/error_budget.py).  Reading channels [0, C) alone is the plain
-                                  fp16 activation. */
-    int32_t dst_plane, dst2_plane; /* plane strides (channels, multiples of 8) of dst / dst2 when planes == 3 */
+                                  fp16 activation.
+                                  2 = hi and lo only: the consumer reads the hi plane twice (mcamd_conv_geom.x_wrap),
+                                  4 instead of 6 bytes written per activation. */
+    int32_t dst_plane, dst2_plane; /* plane strides (channels, multiples of 8) of dst / dst2 when planes >= 2 */
     int32_t dst_pad, dst2_pad; /* 0 / 1: dst, dst2 are in the padded / the shared-halo form (each at its own resolution) */
     const float* border;       /* optional fp32 [16][C], NULL = none: added to the raw conv output before the
                                   affine step, row = border class of the pixel (bit 0: h == 0, bit 1: h == H-1,
@@ -374,7 +382,8 @@ typedef struct mcamd_stem_block_desc {
                                              mcamd_act_desc.planes: hi | lo | hi in three ADJACENT 32-channel planes
                                              [dst_choff, dst_choff + 96) -- the "mixed" precision mode keeps plain fp16
                                              operands on this block (image and weights: 5.2e-4 -> 5.4e-4 on the logits,
-                                             tools/error_budget.py) but hands its consumer an unrounded activation */
+                                             tools/error_budget.py) but hands its consumer an unrounded activation;
+                                             2 = hi | lo in [dst_choff, dst_choff + 64) (consumer with x_wrap = 64) */
 } mcamd_stem_block_desc;
 size_t mcamd_stem_block_workspace_bytes(void);
 int mcamd_stem_block_fwd(const mcamd_stem_block_desc* d, void* workspace, size_t workspace_bytes, void* stream);

@@ -17,7 +17,7 @@ class McamdError(RuntimeError):
 class ConvGeom(C.Structure):
     _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("ksize", C.c_int32),
                 ("cin", C.c_int32), ("cout", C.c_int32), ("x_ld", C.c_int32), ("x_choff", C.c_int32),
-                ("stem", C.c_int32), ("pad", C.c_int32)]
+                ("stem", C.c_int32), ("pad", C.c_int32), ("x_wrap", C.c_int32)]
 
 
 class ConvEpilogue(C.Structure):

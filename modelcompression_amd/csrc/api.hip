@@ -57,8 +57,14 @@ static int check_geom(const mcamd_conv_geom* g, const char* what) {
                       "%s: stem form needs cin=3, ksize=3, x_ld=4, x_choff=0", what);
     } else {
         MCAMD_REQUIRE(g->x_ld % 8 == 0 && g->x_choff % 8 == 0, "%s: x_ld / x_choff must be multiples of 8", what);
-        MCAMD_REQUIRE(g->x_choff + cin_tap_of(g) <= g->x_ld, "%s: x channel slice [%d, %d) exceeds x_ld %d", what,
-                      g->x_choff, g->x_choff + cin_tap_of(g), g->x_ld);
+        const int span = g->x_wrap > 0 ? g->x_wrap : cin_tap_of(g);
+        MCAMD_REQUIRE(g->x_choff + span <= g->x_ld, "%s: x channel slice [%d, %d) exceeds x_ld %d", what,
+                      g->x_choff, g->x_choff + span, g->x_ld);
+    }
+    if (g->x_wrap != 0) {
+        const int ct = cin_tap_of(g), kb = ct % 64 == 0 ? 64 : 32;   // kblock_of(ct)
+        MCAMD_REQUIRE(!g->stem && g->x_wrap > 0 && g->x_wrap % 64 == 0 && g->x_wrap % kb == 0 && g->cin == g->x_wrap / 2 * 3 && ct == g->cin,
+                      "%s: x_wrap %d needs cin = 3 P, x_wrap = 2 P, P %% 32 == 0 (cin %d)", what, g->x_wrap, g->cin);
     }
     return MCAMD_OK;
 }
@@ -457,6 +463,9 @@ extern "C" int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const voi
     a.kb = kblock_of(a.cin_tap);
     a.ktot = a.ntaps * a.cin_tap;
     fill_taps(g->ksize, g->stem, a.x_row_stride, g->x_ld, a.tap_off);
+    a.wrap = g->x_wrap > 0 ? g->x_wrap : 0x7fffffff;
+    MCAMD_REQUIRE(g->x_wrap == 0 || (epi && (epi->mode == MCAMD_EPI_RAW_F32 || epi->mode == MCAMD_EPI_NCHW_F32)),
+                  "conv_fwd: x_wrap goes with the fp32 epilogues (modes 3 and 1)");
     const bool stem_direct = epi && mcamd_stem_direct_ok(g->stem, g->cout, epi->mode);
     const bool wres = epi && epi->dst_mode == MCAMD_DST_PLAIN && g->pad == 0 &&
                       mcamd_wres_ok(g->ksize, g->stem, g->cout, a.cin_tap, a.ktot, g->B, g->H, g->W, epi->mode);
@@ -483,6 +492,7 @@ extern "C" int mcamd_conv_dgrad(const mcamd_conv_geom* g, const void* dy, int32_
         return mcamd_rec_push(stream, [=](void* s) { return mcamd_conv_dgrad(&g_, dy, dy_ld, dy_choff, wp_dgrad, &e_, s); });
     }
     if (check_geom(g, "conv_dgrad")) return MCAMD_EINVAL;
+    MCAMD_REQUIRE(g->x_wrap == 0, "conv_dgrad: x_wrap is a forward-only field");
     MCAMD_REQUIRE(!g->stem, "conv_dgrad: the stem layer has no input gradient");
     MCAMD_REQUIRE(dy && wp_dgrad, "conv_dgrad: null input");
     int cout_p = cout_p_of(g);
@@ -500,6 +510,7 @@ extern "C" int mcamd_conv_dgrad(const mcamd_conv_geom* g, const void* dy, int32_
     a.M = g->B * g->H * g->W;
     a.N = g->cin;
     a.cin_tap = cout_p;
+    a.wrap = 0x7fffffff;
     a.ntaps = g->ksize * g->ksize;
     a.kb = kblock_of(a.cin_tap);
     a.ktot = a.ntaps * a.cin_tap;
@@ -543,6 +554,7 @@ extern "C" int mcamd_conv_wgrad(const mcamd_conv_geom* g, const void* x, const v
         });
     }
     if (check_geom(g, "conv_wgrad")) return MCAMD_EINVAL;
+    MCAMD_REQUIRE(g->x_wrap == 0, "conv_wgrad: x_wrap is a forward-only field");
     MCAMD_REQUIRE(x && dy && dw_oihw && workspace, "conv_wgrad: null argument");
     MCAMD_REQUIRE(grad_scale > 0.f, "conv_wgrad: grad_scale must be positive");
     const int* rmap = map ? (const int*)map->rows : nullptr;

@@ -141,12 +141,12 @@ __device__ __forceinline__ void store_act(half_t* p, int plane, const float* v) 
 #pragma unroll
     for (int i = 0; i < 8; ++i) hi[i] = sat_half(v[i]);
     *(h8_t*)p = hi;
-    if (PL == 3) {
+    if (PL >= 2) {
         h8_t lo;
 #pragma unroll
         for (int i = 0; i < 8; ++i) lo[i] = (half_t)(v[i] - (float)hi[i]);   // exact difference, one rounding; |lo| <= ulp(hi)/2
         *(h8_t*)(p + plane) = lo;
-        *(h8_t*)(p + 2 * plane) = hi;
+        if (PL == 3) *(h8_t*)(p + 2 * plane) = hi;      // (PL == 2: the consumer wraps its third K part onto the hi plane)
     }
 }
 // offset of pixel (b, h, w) from the buffer pointer; pw = 2: padded NHWC, pw = 1: shared-halo form (include/mcamd.h)
@@ -775,15 +775,15 @@ extern "C" int mcamd_bn_act_fwd(const mcamd_act_desc* d, void* stream) {
     MCAMD_REQUIRE(d->mode != MCAMD_DST_PLAIN || !d->dst2, "bn_act_fwd: dst2 only with pool/reorg");
     MCAMD_REQUIRE(d->y_dtype == 0 || d->y_dtype == 1, "bn_act_fwd: y_dtype %d (0 = fp16, 1 = fp32)", d->y_dtype);
     const int planes = d->planes == 0 ? 1 : d->planes;
-    MCAMD_REQUIRE(planes == 1 || planes == 3, "bn_act_fwd: planes must be 1 or 3 (got %d)", d->planes);
-    if (planes == 3) {
+    MCAMD_REQUIRE(planes >= 1 && planes <= 3, "bn_act_fwd: planes must be 1, 2 or 3 (got %d)", d->planes);
+    if (planes >= 2) {
         const int span = d->mode == MCAMD_DST_REORG ? 4 * d->C : d->C;
-        MCAMD_REQUIRE(d->dst_plane % 8 == 0 && d->dst_plane >= span && d->dst_choff + 2 * d->dst_plane + span <= d->dst_ld,
-                      "bn_act_fwd: 3 planes of stride %d (+ offset %d, %d channels) do not fit dst_ld %d", d->dst_plane,
+        MCAMD_REQUIRE(d->dst_plane % 8 == 0 && d->dst_plane >= span && d->dst_choff + (planes - 1) * d->dst_plane + span <= d->dst_ld,
+                      "bn_act_fwd: %d planes of stride %d (+ offset %d, %d channels) do not fit dst_ld %d", planes, d->dst_plane,
                       d->dst_choff, span, d->dst_ld);
         MCAMD_REQUIRE(!d->dst2 || (d->dst2_plane % 8 == 0 && d->dst2_plane >= d->C &&
-                                   d->dst2_choff + 2 * d->dst2_plane + d->C <= d->dst2_ld),
-                      "bn_act_fwd: 3 planes of stride %d do not fit dst2_ld %d", d->dst2_plane, d->dst2_ld);
+                                   d->dst2_choff + (planes - 1) * d->dst2_plane + d->C <= d->dst2_ld),
+                      "bn_act_fwd: %d planes of stride %d do not fit dst2_ld %d", planes, d->dst2_plane, d->dst2_ld);
     }
     ActArgs a;
     a.dst_plane = d->dst_plane, a.dst2_plane = d->dst2_plane;
@@ -810,8 +810,10 @@ extern "C" int mcamd_bn_act_fwd(const mcamd_act_desc* d, void* stream) {
 #define ACT_INST(MODE_, FIXED_)                                                                                         \
     do {                                                                                                                \
         if (y32 && planes == 3) hipLaunchKernelGGL((bn_act_fwd_kernel<MODE_, FIXED_, true, 3>), dim3(grid), dim3(256), 0, st, a);       \
+        else if (y32 && planes == 2) hipLaunchKernelGGL((bn_act_fwd_kernel<MODE_, FIXED_, true, 2>), dim3(grid), dim3(256), 0, st, a);  \
         else if (y32) hipLaunchKernelGGL((bn_act_fwd_kernel<MODE_, FIXED_, true, 1>), dim3(grid), dim3(256), 0, st, a);                 \
         else if (planes == 3) hipLaunchKernelGGL((bn_act_fwd_kernel<MODE_, FIXED_, false, 3>), dim3(grid), dim3(256), 0, st, a);        \
+        else if (planes == 2) hipLaunchKernelGGL((bn_act_fwd_kernel<MODE_, FIXED_, false, 2>), dim3(grid), dim3(256), 0, st, a);        \
         else hipLaunchKernelGGL((bn_act_fwd_kernel<MODE_, FIXED_, false, 1>), dim3(grid), dim3(256), 0, st, a);                         \
     } while (0)
 #define ACT_CASE(MODE_)                   \

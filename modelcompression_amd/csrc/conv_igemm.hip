@@ -126,7 +126,9 @@ void igemm_kernel(IgemmArgs a) {
             const int sub = a.kb / BK > 0 ? a.kb / BK : 1, per_block = a.ntaps * sub;
             const int cb = q / per_block, r = q - cb * per_block;
             const int tap = r / sub;
-            int koff = a.tap_off[tap] + cb * a.kb + (r - tap * sub) * BK;
+            int cbo = cb * a.kb;
+            if (cbo >= a.wrap) cbo -= a.wrap;      // mcamd_conv_geom.x_wrap: the third split part reads the hi plane again
+            int koff = a.tap_off[tap] + cbo + (r - tap * sub) * BK;
             char* sa = smem + buf * STAGE_BYTES;
             char* sb = sa + A_SLOTS * 16;
 #pragma unroll

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
         // channel offset of its block, tap, offset inside the block, linear chunk index
         int st_cb = 0, st_tap = 0, st_c = 0, st_q = 0;
         auto stage_next = [&]() {
-            const int koff = (a.tap_off[st_tap] + st_cb + st_c) * 2;
+            const int koff = (a.tap_off[st_tap] + (st_cb >= a.wrap ? st_cb - a.wrap : st_cb) + st_c) * 2;   // (x_wrap: hi plane again)
             const int woff = st_q * (BK * 2);
             char* sa = smem + (st_q & (NST - 1)) * STAGE_BYTES;
             char* sb = sa + A_SLOTS * 16;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
             // ---------------- memory phase: wait for chunk p+1, read the fragments of chunk p ----------------
             __builtin_amdgcn_sched_barrier(0);   // nothing of this phase is scheduled above the barrier that opens it
             const bool more = p + NST - 1 < nchunks;
-            const int koff = (a.tap_off[st_tap] + st_cb + st_c) * 2;
+            const int koff = (a.tap_off[st_tap] + (st_cb >= a.wrap ? st_cb - a.wrap : st_cb) + st_c) * 2;   // (x_wrap: hi plane again)
             const int woff = st_q * (BK * 2);
             char* sa = smem + (st_q & (NST - 1)) * STAGE_BYTES;
             char* sb = sa + A_SLOTS * 16;

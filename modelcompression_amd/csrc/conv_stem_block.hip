@@ -339,10 +339,8 @@ __global__ __launch_bounds__(256) void stem_block_fwd_kernel(StemBlockArgs a) {
                 const half_t hi = (half_t)m;
                 half_t* tp = tw + pooled_of(q, kg) * TW + pl;
                 tp[0] = hi;
-                if (PL == 3) {                        // exact difference, one rounding; a consumer with split operands reads all three
-                    tp[32] = (half_t)(m - (float)hi);
-                    tp[64] = hi;
-                }
+                if (PL >= 2) tp[32] = (half_t)(m - (float)hi);   // exact difference, one rounding; a consumer with split operands reads hi and lo
+                if (PL == 3) tp[64] = hi;                          // (PL == 2: the consumer wraps its third K part onto the hi plane)
             }
 #pragma unroll
             for (int k = 0; k < PL; ++k) {
@@ -587,8 +585,8 @@ extern "C" int mcamd_stem_block_fwd(const mcamd_stem_block_desc* d, void* worksp
         return mcamd_rec_push(stream, [=](void* s) { return mcamd_stem_block_fwd(&d_, workspace, workspace_bytes, s); });
     }
     if (check_desc(d, "stem_block_fwd")) return MCAMD_EINVAL;
-    MCAMD_REQUIRE(d->planes == 0 || d->planes == 1 || d->planes == 3, "stem_block_fwd: planes must be 1 or 3 (got %d)", d->planes);
-    const int span = d->planes == 3 ? 96 : 32;
+    MCAMD_REQUIRE(d->planes >= 0 && d->planes <= 3, "stem_block_fwd: planes must be 1, 2 or 3 (got %d)", d->planes);
+    const int span = d->planes >= 2 ? 32 * d->planes : 32;
     MCAMD_REQUIRE(d->dst && d->dst_ld % 8 == 0 && d->dst_choff % 8 == 0 && d->dst_choff + span <= d->dst_ld,
                   "stem_block_fwd: output slice [%d, %d) does not fit dst_ld %d", d->dst_choff, d->dst_choff + span, d->dst_ld);
     const Carve c = carve();
@@ -625,6 +623,7 @@ extern "C" int mcamd_stem_block_fwd(const mcamd_stem_block_desc* d, void* worksp
     const int grid = (int)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
     const int un = MCAMD_ENV_INT("MCAMD_STEM_FWD_UN", 4);   // tuning switch
     if (d->planes == 3) hipLaunchKernelGGL((stem_block_fwd_kernel<2, 3>), dim3(grid), dim3(256), 0, st, a);
+    else if (d->planes == 2) hipLaunchKernelGGL((stem_block_fwd_kernel<2, 2>), dim3(grid), dim3(256), 0, st, a);
     else if (un == 4) hipLaunchKernelGGL((stem_block_fwd_kernel<4, 1>), dim3(grid), dim3(256), 0, st, a);
     else if (un == 1) hipLaunchKernelGGL((stem_block_fwd_kernel<1, 1>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((stem_block_fwd_kernel<2, 1>), dim3(grid), dim3(256), 0, st, a);

@@ -35,6 +35,7 @@ struct IgemmArgs {
     void* y2;
     int y2_ld, y2_choff;
     int concurrent;  // mcamd_conv_epilogue.concurrent (dgrad): tiles chosen for CU-time, see pick_tile
+    int wrap;        // mcamd_conv_geom.x_wrap (INT_MAX = none): channel blocks >= wrap are read `wrap` channels lower
 };
 
 struct StemArgs {        // conv_stem.hip: forward of the 3-channel first layer

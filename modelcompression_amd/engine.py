@@ -233,7 +233,16 @@ class Engine:
             return len(self.bufs) - 1
         self._pad_for = pad_for
 
-        planes = 3 if self.precise else 1      # split (hi | lo | hi) activation storage
+        # Split activation storage of the precise modes: hi | lo planes, the consumer's third K part (x_hi * w_lo) wraps back
+        # onto the hi plane (mcamd_conv_geom.x_wrap) -- when every tensor's channel count is a multiple of 32 (K blocks must
+        # not straddle the wrap); otherwise (physically slim models) three planes hi | lo | hi.  The network input always has
+        # three (9 channels).
+        planes = 1
+        if self.precise:
+            chans = [shape[t][0] for ci in conv_inds for t in fused[ci][1:] if t is not None and consumers.get(t)]
+            chans += [shape[srcs[i][0]][0] + shape[srcs[i][1]][0] for i, (t, _) in enumerate(bops) if t == "route" and len(srcs[i]) == 2]
+            planes = 2 if (all(c % 32 == 0 for c in chans) and os.environ.get("MCAMD_TWO_PLANES", "1") == "1") else 3
+        self.act_planes = planes
 
         for ind, (t, _) in enumerate(bops):
             if t == "route" and len(srcs[ind]) == 2:
@@ -265,7 +274,7 @@ class Engine:
         # output, only to fill the workspace its backward reads (Gram sums) and its own self-consistent coefficients.
         self.stem_shadow = bool(self.precise and self.for_training and not self.stem and stem_block_ok
                                 and os.environ.get("MCAMD_STEM_SHADOW", "1") == "1")
-        ld0 = 4 if self.stem else ops.round_up(cin0 * planes, 32)
+        ld0 = 4 if self.stem else ops.round_up(cin0 * (3 if self.precise else 1), 32)
         place[-1] = _T(new_buf(B, H0, W0, ld0), ld0, 0, cin0, H0, W0, cin0 if (self.precise and not self.stem) else 0)
         materialized = set()
         for ci in conv_inds:
@@ -386,8 +395,9 @@ class Engine:
         for lay in self.layers:
             g = lay.geom
             # forward geometry: the K-concatenated problem [x_hi | x_lo | x_hi] x [w_hi | w_hi | w_lo]
+            wrap = 2 * lay.tin.ps if (self.act_planes == 2 and lay.li > 0) else 0      # (the network input keeps three planes)
             lay.geom_f = g if lay.level == 1 else ops.geom(B, lay.H, lay.W, lay.k, lay.level * lay.cin, lay.cout,
-                                                           lay.tin.ld, 0, 0, lay.pad)
+                                                           lay.tin.ld, 0, 0, lay.pad, wrap)
             nf, _ = ops.packed_elems(lay.geom_f)
             _, nd = ops.packed_elems(g)
             # zero-initialised: the one-launch packer writes real entries only (pad rows / channels stay zero)
@@ -898,7 +908,7 @@ class Engine:
                             bn.running_mean, bn.running_var, training, lay.scale, lay.shift, lay.mean, lay.invstd, lay.slope,
                             self.bufs[t.buf], t.ld, t.choff, lay.stem_ws if lay.fused_stem else None,
                             momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps, cout=lay.cout,
-                            planes=3 if self.precise else 1)
+                            planes=self.act_planes)
                 continue
             if training and lay.stem_shadow:
                 # the fused first block on plain operands into a scratch output: fills the workspace and the coefficients
@@ -921,7 +931,7 @@ class Engine:
                                self.bufs[t.buf], t.ld, t.choff,
                                self.bufs[t2.buf] if t2 is not None else None,
                                t2.ld if t2 is not None else 0, t2.choff if t2 is not None else 0, border=lay.border,
-                               planes=3, dst_plane=t.ps, dst2_plane=t2.ps if t2 is not None else 0,
+                               planes=self.act_planes, dst_plane=t.ps, dst2_plane=t2.ps if t2 is not None else 0,
                                dst_pad=self._pad_for(t.W), dst2_pad=self._pad_for(t2.W) if t2 is not None else 0)
                 continue
             if (not training and self.fuse_eval and lay.perm is None and lay.border is None

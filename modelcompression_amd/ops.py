@@ -65,8 +65,8 @@ def padded_view(buf, B, H, W, ld, pad=None):
     return buf[: B * (H + 2) * (W + 2) * ld].view(B, H + 2, W + 2, ld)
 
 
-def geom(B, H, W, ksize, cin, cout, x_ld, x_choff=0, stem=0, pad=0):
-    return ConvGeom(B, H, W, ksize, cin, cout, x_ld, x_choff, stem, pad)
+def geom(B, H, W, ksize, cin, cout, x_ld, x_choff=0, stem=0, pad=0, x_wrap=0):
+    return ConvGeom(B, H, W, ksize, cin, cout, x_ld, x_choff, stem, pad, x_wrap)
 
 
 def packed_elems(g):

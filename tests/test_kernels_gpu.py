@@ -373,6 +373,46 @@ def test_stem_conv_f32(dev, B, H, W, masked):
         ops.stem_conv_f32(x.to(dev), torch.zeros(16, 3, 3, 3, device=dev), None, scratch, y2, 32, None)
 
 
+@pytest.mark.parametrize("B,H,W,C_,cout,k", [(2, 12, 20, 32, 64, 3), (3, 13, 13, 256, 512, 3), (4, 10, 14, 512, 256, 1), (2, 9, 9, 64, 40, 3)])
+def test_split_forward_two_planes_equals_three(dev, B, H, W, C_, cout, k):
+    """mcamd_conv_geom.x_wrap: the split-operand forward on TWO activation planes [x_hi | x_lo] (third K part wrapped back
+    onto the hi plane) gives bit for bit the fp32 raw output and statistics of the three-plane form [x_hi | x_lo | x_hi]
+    (same K order, same operands), in the 128-wide and the ping-pong kernels; and both are within 2e-6 of fp64."""
+    gen = torch.Generator().manual_seed(C_ + cout)
+    x = torch.randn(B, C_, H, W, generator=gen)
+    w = torch.randn(cout, C_, k, k, generator=gen) * (2.0 / (C_ * k * k)) ** 0.5
+    hi = x.half().float()
+    lo = (x - hi).half().float()
+    ld3, ld2 = 3 * C_, 2 * C_
+    x3 = ops.alloc_padded(B, H, W, ld3, dev)
+    x2 = ops.alloc_padded(B, H, W, ld2, dev)
+    for buf, ld, parts in ((x3, ld3, (hi, lo, hi)), (x2, ld2, (hi, lo))):
+        for i, part in enumerate(parts):
+            ops.nchw_to_padded(part.to(dev).contiguous(), buf, ld, i * C_)
+    g3 = ops.geom(B, H, W, k, 3 * C_, cout, ld3)
+    g2 = ops.geom(B, H, W, k, 3 * C_, cout, ld2, x_wrap=2 * C_)
+    wp = torch.zeros(ops.packed_elems(g3)[0], dtype=torch.float16, device=dev)
+    wdev = w.to(dev).contiguous()
+    ops.pack_many(*ops.pack_table([dict(w=wdev, mask=None, rows=None, cols=None, cout=cout, cin=C_, ksize=k, dst_fwd=wp,
+                                        dst_dgrad=None, split=True)], dev))
+    outs = []
+    for g, xb in ((g3, x3), (g2, x2)):
+        y = torch.zeros(B * H * W * cout, device=dev)
+        stats = torch.zeros(ops.stats_rows(g, L.EPI_RAW_F32), 2, ops.round_up(cout, 256), device=dev)
+        ops.conv_fwd_raw32(g, xb, wp, y, cout, 0, stats)
+        outs.append((y, stats))
+    assert ops.tile_info(g3) == ops.tile_info(g2)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = F.conv2d(x.double(), w.double(), None, 1, (k - 1) // 2)
+    got = outs[1][0].view(B, H, W, cout).permute(0, 3, 1, 2).cpu()
+    assert rel_l2(got, ref) < 2e-6
+    # the field is forward-only and needs whole K blocks per plane
+    with pytest.raises(L.McamdError):
+        ops.conv_fwd_raw(g2, x2, wp, torch.zeros(B * H * W * cout, dtype=torch.float16, device=dev), cout, 0, None)
+    with pytest.raises(L.McamdError):
+        ops.conv_fwd_raw32(ops.geom(B, H, W, k, 3 * C_, cout, ld2, x_wrap=2 * C_ - 16), x2, wp, outs[0][0], cout, 0, None)
+
+
 def test_pack_many_split_operands(dev):
     """mcamd_pack_job.split: the one-launch packer writes the [w_hi | w_hi | w_lo] forward packing of the split-operand
     precisions bit for bit as the per-layer packing of torch.cat([hi, hi, w * mask - hi], 1) does (what the engine
