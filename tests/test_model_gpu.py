@@ -572,6 +572,34 @@ def test_layerwise_teacher_forced_yolov2(dev):
     _teacher_forced(dev, YOLOV2_VOC_CFG, 1, 5, masked=False)
 
 
+def test_fused_eval_epilogue_is_not_slower_than_two_passes(dev, setenv):
+    """Guard: the fused inference epilogue (BN + LeakyReLU + pool / reorg in the convolution, plain fp16) must pay -- 4.8 ms
+    against 5.2 ms per B=128 forward.  (A two-plane variant of that epilogue written as a run-time loop inside the same
+    kernel instances once spilled 9-121 registers in them and made this path 2x SLOWER, 10.8 ms, with every parity test
+    green.)  Bar: not more than 1.15x the unfused time."""
+    import time
+    m = nets.Darknet(YOLOV2_VOC_CFG)
+    m.load_state_dict(O.init_state(O.parse_cfg(YOLOV2_VOC_CFG), seed=1))
+    m.to(dev).eval()
+    m.precision = "fp16"
+    x = torch.rand(64, 3, 416, 416, generator=torch.Generator().manual_seed(2)).to(dev)
+    ms = {}
+    for fuse in ("0", "1"):
+        setenv("MCAMD_FUSE_EVAL", fuse)
+        m._engines = {}
+        with torch.no_grad():
+            for _ in range(3):
+                m(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(15):
+                m(x)
+            torch.cuda.synchronize()
+        ms[fuse] = (time.perf_counter() - t0) / 15 * 1e3
+    print("fp16 eval forward at B=64: fused %.2f ms, two passes %.2f ms" % (ms["1"], ms["0"]))
+    assert ms["1"] < 1.15 * ms["0"]
+
+
 def test_yolov2_eval_logits_vs_golden(dev, tmp_path):
     """Config 1: seeded full-size YOLOv2-VOC, .weights round trip, eval logits vs the reference's."""
     import hashlib
