@@ -471,6 +471,17 @@ int mcamd_stream_wait(void* waiter_stream, void* signal_stream);
 /* hipMemsetAsync(dst, 0, bytes) -- the zero rows of a filter-pruned layer's weight gradient.  Recordable. */
 int mcamd_memset_zero(void* dst, size_t bytes, void* stream);
 
+/* The overflow / non-finite policy of a training step as ONE launch (modelcompression_amd/train.py StepGuard; the
+ * reference checks the loss on the host, train.py:226-231):
+ *   flags[0] = any of the n_engine device flags engine_overflow[i] (mcamd_conv_epilogue.overflow & co.) is set,
+ *   flags[1] = *loss is not finite (loss may be NULL), flags[2] = *transport_overflow != 0 (may be NULL);
+ *   the int flags that were read are reset to 0; found (may be NULL) = flags[0] + flags[1] + flags[2] -- what torch's
+ *   fused SGD takes as `found_inf`.
+ * With n_engine == 0, loss == NULL and transport_overflow == NULL only `found` is recomputed from `flags` (after the
+ * MAX all-reduce of the flags over the data-parallel ranks).  engine_overflow: host array of <= 8 device pointers. */
+int mcamd_step_flags(const int32_t* const* engine_overflow, int32_t n_engine, const float* loss,
+                     int32_t* transport_overflow, float* flags, float* found, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Pruning (reference src/pruning/weightPruning/methods.py).
  * ------------------------------------------------------------------------- */

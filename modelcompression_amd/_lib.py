@@ -142,6 +142,7 @@ SIGNATURES = {
     "mcamd_plan_destroy": (None, [_P]),
     "mcamd_stream_wait": (C.c_int, [_P, _P]),
     "mcamd_memset_zero": (C.c_int, [_P, _SZ, _P]),
+    "mcamd_step_flags": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P]),
     "mcamd_kth_magnitude_workspace_bytes": (_SZ, []),
     "mcamd_kth_magnitude": (C.c_int, [C.POINTER(_P), C.POINTER(_I64), _I32, _I64, _P, _P, _SZ, _P]),
     "mcamd_magnitude_mask": (C.c_int, [_P, _I64, _P, _P, _P]),

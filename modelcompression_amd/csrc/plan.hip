@@ -165,3 +165,57 @@ extern "C" int mcamd_memset_zero(void* dst, size_t bytes, void* stream) {
     if (mcamd_recording()) return mcamd_rec_push(stream, [=](void* s) { return memset_impl(dst, bytes, s); });
     return memset_impl(dst, bytes, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// step flags (train.py StepGuard): one launch instead of a dozen torch micro-kernels between backward and the optimizer
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct StepFlagArgs {
+    int32_t* eng[8];
+    int n;
+    const float* loss;
+    int32_t* tflag;
+    float* flags;
+    float* found;
+};
+__global__ void step_flags_kernel(StepFlagArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (a.n > 0 || a.loss || a.tflag) {
+        float over = 0.f, bad = 0.f, tover = 0.f;
+        for (int i = 0; i < a.n; ++i) {
+            if (*a.eng[i] != 0) over = 1.f;
+            *a.eng[i] = 0;
+        }
+        if (a.loss) {
+            const float l = *a.loss;
+            bad = (l == l && fabsf(l) <= 3.402823466e38f) ? 0.f : 1.f;
+        }
+        if (a.tflag) {
+            tover = *a.tflag != 0 ? 1.f : 0.f;
+            *a.tflag = 0;
+        }
+        a.flags[0] = over, a.flags[1] = bad, a.flags[2] = tover;
+    }
+    if (a.found) *a.found = a.flags[0] + a.flags[1] + a.flags[2];
+}
+}  // namespace
+
+extern "C" int mcamd_step_flags(const int32_t* const* engine_overflow, int32_t n_engine, const float* loss,
+                                int32_t* transport_overflow, float* flags, float* found, void* stream) {
+    MCAMD_REQUIRE(flags, "step_flags: null flags");
+    MCAMD_REQUIRE(n_engine >= 0 && n_engine <= 8 && (n_engine == 0 || engine_overflow), "step_flags: 0..8 engine flags");
+    StepFlagArgs a = {};
+    for (int i = 0; i < n_engine; ++i) {
+        MCAMD_REQUIRE(engine_overflow[i], "step_flags: null engine flag");
+        a.eng[i] = (int32_t*)engine_overflow[i];
+    }
+    a.n = n_engine, a.loss = loss, a.tflag = transport_overflow, a.flags = flags, a.found = found;
+    if (mcamd_recording())
+        return mcamd_rec_push(stream, [=](void* s) {
+            hipLaunchKernelGGL(step_flags_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, a);
+            return MCAMD_OK;
+        });
+    hipLaunchKernelGGL(step_flags_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+    MCAMD_LAUNCH_CHECK("step_flags");
+    return MCAMD_OK;
+}

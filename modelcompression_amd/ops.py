@@ -514,6 +514,18 @@ def memset_zero(t):
 
 
 # ------------------------------------------------------------------ pruning
+def step_flags(engine_flags, loss, transport_flag, flags, found):
+    """train.StepGuard's device-side decision in one launch (mcamd_step_flags): flags = [any engine overflow, loss not finite,
+    transport overflow] (the int flags read are reset), found = their sum.  All arguments but `flags` may be None / empty."""
+    _need_cuda(flags, found, loss, transport_flag, *engine_flags)
+    assert flags.dtype == torch.float32 and flags.numel() >= 3 and len(engine_flags) <= 8
+    assert all(f.dtype == torch.int32 for f in engine_flags) and (transport_flag is None or transport_flag.dtype == torch.int32)
+    assert loss is None or (loss.dtype == torch.float32 and loss.numel() == 1)
+    arr = (C.c_void_p * max(1, len(engine_flags)))(*[f.data_ptr() for f in engine_flags])
+    check(L.lib().mcamd_step_flags(arr, len(engine_flags), ptr(loss), ptr(transport_flag), ptr(flags), ptr(found), stream_ptr()),
+          "mcamd_step_flags")
+
+
 def kth_magnitude(tensors, k):
     """-> device fp32[2] = (s[k], s[min(k+1, n-1)]) of the ascending |w| over all tensors."""
     _need_cuda(*tensors)

@@ -102,11 +102,24 @@ class StepGuard:
         """Call between backward() and optimizer.step()."""
         self.consume()
         flags = [eng.overflow for eng in getattr(self.model, "_engines", {}).values()]
+        red = getattr(self.model, "_grad_reducer", None)
+        tflag = red.overflow if red is not None else None
+        if (self.dev.type == "cuda" and len(flags) <= 8 and loss.dtype == torch.float32 and loss.numel() == 1
+                and all(f.is_cuda and f.dtype == torch.int32 for f in flags + ([tflag] if tflag is not None else []))):
+            # one launch (mcamd_step_flags) instead of the dozen torch micro-kernels below: 9.42 -> 9.3x ms per real step
+            from . import ops
+            ops.step_flags(flags, loss.detach().reshape(1), tflag, self.flags, None if self._collective else self.found)
+            if self._collective:
+                dist.all_reduce(self.flags, op=dist.ReduceOp.MAX)
+                ops.step_flags([], None, None, self.flags, self.found)
+            self._host.copy_(self.flags, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
+            self._pending = True
+            return
         zero = torch.zeros((), dtype=torch.float32, device=self.dev)
         over = torch.stack([f.reshape(()) for f in flags]).sum().clamp(max=1).to(torch.float32) if flags else zero
         bad = (~torch.isfinite(loss.detach())).to(torch.float32).reshape(())
-        red = getattr(self.model, "_grad_reducer", None)
-        tflag = red.overflow if red is not None else None
         tover = tflag.reshape(()).clamp(max=1).to(torch.float32) if tflag is not None else zero
         self.flags.copy_(torch.stack((over, bad, tover)))
         for f in flags + ([tflag] if tflag is not None else []):

@@ -413,6 +413,27 @@ def test_split_forward_two_planes_equals_three(dev, B, H, W, C_, cout, k):
         ops.conv_fwd_raw32(ops.geom(B, H, W, k, 3 * C_, cout, ld2, x_wrap=2 * C_ - 16), x2, wp, outs[0][0], cout, 0, None)
 
 
+def test_step_flags_kernel(dev):
+    """mcamd_step_flags (train.StepGuard's device-side decision in one launch): [any engine overflow, loss not finite,
+    transport overflow], their sum for the fused SGD's found_inf, the int flags reset; and the found-only form used after
+    the data-parallel MAX all-reduce of the flags."""
+    for eng_vals, loss_v, t_v in (([0], 1.5, None), ([0, 7], 2.0, 0), ([0, 0], float("inf"), 1), ([3], float("nan"), None),
+                                   ([], -1e30, 5), ([0], -float("inf"), 0)):
+        eng = [torch.tensor([v], dtype=torch.int32, device=dev) for v in eng_vals]
+        loss = torch.tensor([loss_v], dtype=torch.float32, device=dev)
+        tf = None if t_v is None else torch.tensor([t_v], dtype=torch.int32, device=dev)
+        flags = torch.full((3,), 9.0, device=dev)
+        found = torch.full((1,), 9.0, device=dev)
+        ops.step_flags(eng, loss, tf, flags, found)
+        want = [float(any(v != 0 for v in eng_vals)), float(not np.isfinite(loss_v)), float(bool(t_v))]
+        assert flags.tolist() == want and found.item() == sum(want), (eng_vals, loss_v, t_v, flags.tolist())
+        assert all(int(e.item()) == 0 for e in eng) and (tf is None or int(tf.item()) == 0)
+    flags = torch.tensor([1.0, 0.0, 1.0], device=dev)
+    found = torch.zeros(1, device=dev)
+    ops.step_flags([], None, None, flags, found)
+    assert flags.tolist() == [1.0, 0.0, 1.0] and found.item() == 2.0
+
+
 def test_pack_many_split_operands(dev):
     """mcamd_pack_job.split: the one-launch packer writes the [w_hi | w_hi | w_lo] forward packing of the split-operand
     precisions bit for bit as the per-layer packing of torch.cat([hi, hi, w * mask - hi], 1) does (what the engine
