@@ -48,8 +48,10 @@ __global__ __launch_bounds__(NTHR) void region_loss_kernel(RegionArgs a) {
     __shared__ int gcell[MAXT], gbest[MAXT], gwriter[MAXT];
     __shared__ int nvalid;
     __shared__ float red[NTHR];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int HW = a.H * a.W, N = a.A * HW, K = 5 + a.C;
+    // one workgroup per (image, anchor): 320 workgroups for B=64 (one per image ran 33 us on 64 of the 256 CUs); every
+    // workgroup builds the image's target list itself (50 rows)
+    const int b = blockIdx.x, an_blk = blockIdx.y, tid = threadIdx.x;
+    const int HW = a.H * a.W, K = 5 + a.C;
     const float* tg = a.target + (long long)b * MAXT * 5;
     if (tid == 0) {
         int t = 0;
@@ -87,8 +89,8 @@ __global__ __launch_bounds__(NTHR) void region_loss_kernel(RegionArgs a) {
     const float inv_nb = 1.0f / (float)a.B;
     float lsum = 0.f;
     int correct = 0;
-    for (int n = tid; n < N; n += NTHR) {
-        const int an = n / HW, r = n - an * HW, j = r / a.W, i = r - j * a.W;
+    for (int r = tid; r < HW; r += NTHR) {
+        const int an = an_blk, n = an * HW + r, j = r / a.W, i = r - j * a.W;
         const long long base = ((long long)b * a.A * K + (long long)an * K) * HW + r;
         const float o0 = a.out[base], o1 = a.out[base + HW], o2 = a.out[base + 2 * HW], o3 = a.out[base + 3 * HW],
                     o4 = a.out[base + 4 * HW];
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(NTHR) void region_loss_kernel(RegionArgs a) {
         lsum += l;
     }
     // nGT / nCorrect: the reference counts every valid box whose IoU with the prediction at its cell exceeds 0.5
-    if (a.counts && tid < T) {
+    if (a.counts && an_blk == 0 && tid < T) {
         const int n = gcell[tid], an = n / HW, r = n - an * HW, j = r / a.W, i = r - j * a.W;
         const long long base = ((long long)b * a.A * K + (long long)an * K) * HW + r;
         const float px = sigmoidf_(a.out[base]) + (float)i, py = sigmoidf_(a.out[base + HW]) + (float)j;
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(NTHR) void region_loss_kernel(RegionArgs a) {
         if (tid < o) red[tid] += red[tid + o];
         __syncthreads();
     }
-    if (tid == 0) a.partial[b] = red[0] * inv_nb;
+    if (tid == 0) a.partial[b * a.A + an_blk] = red[0] * inv_nb;
 }
 
 __global__ __launch_bounds__(256) void region_loss_sum_kernel(const float* partial, int B, float* loss) {
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void region_loss_sum_kernel(const float* parti
     if (threadIdx.x == 0) *loss = red[0];
 }
 
-extern "C" size_t mcamd_region_loss_workspace_bytes(int32_t B) { return (size_t)(B > 0 ? B : 1) * sizeof(float); }
+extern "C" size_t mcamd_region_loss_workspace_bytes(int32_t B) { return (size_t)(B > 0 ? B : 1) * 8 * sizeof(float); }   // [B][anchors <= 8] partial sums
 
 extern "C" int mcamd_region_loss(const mcamd_region_desc* d, float* loss, float* grad, int32_t* counts, void* workspace,
                                  size_t workspace_bytes, void* stream) {
@@ -190,8 +192,8 @@ extern "C" int mcamd_region_loss(const mcamd_region_desc* d, float* loss, float*
     a.coord_scale = d->coord_scale, a.noobject_scale = d->noobject_scale, a.object_scale = d->object_scale;
     a.class_scale = d->class_scale, a.thresh = d->thresh;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(region_loss_kernel, dim3(d->B), dim3(NTHR), 0, st, a);
-    hipLaunchKernelGGL(region_loss_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, d->B, loss);
+    hipLaunchKernelGGL(region_loss_kernel, dim3(d->B, d->num_anchors), dim3(NTHR), 0, st, a);
+    hipLaunchKernelGGL(region_loss_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, d->B * d->num_anchors, loss);
     MCAMD_LAUNCH_CHECK("region_loss");
     return MCAMD_OK;
 }
