@@ -142,6 +142,7 @@ class Engine:
         self.fold_dead = os.environ.get("MCAMD_FOLD_DEAD", "1") == "1"
         self.bn_narrow_on = os.environ.get("MCAMD_BN_NARROW", "1") == "1"
         self._side_stream = None
+        self._side_concurrent = True
         self._side_ws = None
         # set by the backward kernels when a scaled gradient (grad_scale x dY / dX) had to be clamped to +-65504
         self.overflow = torch.zeros(1, dtype=torch.int32, device=device)
@@ -504,6 +505,7 @@ class Engine:
                 hit = _probe_side_stream(self.device)
                 Engine._SIDE_STREAMS[key] = hit
             self._side_stream = hit[0]
+            self._side_concurrent = hit[1] is not False      # (None = not probed: assumed concurrent)
         return self._side_stream
 
     # ------------------------------------------------------------------ per-kernel timing
@@ -1165,7 +1167,8 @@ class Engine:
                 # picks the tile with the least CU-time.  Not in the per-kernel timing mode, where every launch has the GPU
                 # to itself: the layer table then shows the tile that is fastest alone -- three launches differ)
                 self._timed('dgrad', lay, ops.conv_dgrad_raw, lay.geom_act, lay.dy, lay.cout_p, 0, lay.wd, lay.gin, lay.tin.ld,
-                            lay.tin.choff, overflow=self.overflow, concurrent=self.overlap_wgrad and self.events is None)
+                            lay.tin.choff, overflow=self.overflow,
+                            concurrent=side is not None and self._side_concurrent)
         if side is not None:
             flush()
             ops.stream_wait(main, side)
