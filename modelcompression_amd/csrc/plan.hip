@@ -196,7 +196,9 @@ __global__ void step_flags_kernel(StepFlagArgs a) {
         }
         a.flags[0] = over, a.flags[1] = bad, a.flags[2] = tover;
     }
-    if (a.found) *a.found = a.flags[0] + a.flags[1] + a.flags[2];
+    // torch's fused optimizers skip the update only when *found_inf == 1.0 EXACTLY (fused_adam_utils.cuh / fused SGD:
+    // `if (found_inf_ptr && *found_inf_ptr == 1) return;`): two flags in one step must not add up to 2
+    if (a.found) *a.found = (a.flags[0] != 0.f || a.flags[1] != 0.f || a.flags[2] != 0.f) ? 1.f : 0.f;
 }
 }  // namespace
 

@@ -61,7 +61,7 @@ class StepGuard:
         self.model, self.opt, self.dev, self.log = model, optimizer, dev, log
         self.flags = torch.zeros(3, dtype=torch.float32, device=dev)   # [engine overflow, non-finite loss, transport overflow]
         self.found = torch.zeros(1, dtype=torch.float32, device=dev)
-        optimizer.found_inf = self.found          # torch's fused SGD skips the whole update when this is non-zero
+        optimizer.found_inf = self.found          # torch's fused SGD skips the whole update when this is EXACTLY 1.0
         # momentum buffers exist (zero) from the start: a skipped FIRST step would otherwise leave them uninitialised
         # (torch creates them with empty_like on the first call); zero buffers give the same first update, buf = grad
         for group in optimizer.param_groups:
@@ -126,7 +126,7 @@ class StepGuard:
             f.zero_()
         if self._collective:
             dist.all_reduce(self.flags, op=dist.ReduceOp.MAX)
-        self.found.copy_(self.flags.sum().reshape(1))
+        self.found.copy_(self.flags.amax().clamp(max=1).reshape(1))      # exactly 1.0: the fused SGD tests `== 1`
         self._host.copy_(self.flags, non_blocking=True)
         if self.dev.type == "cuda":
             self._event = torch.cuda.Event()

@@ -298,6 +298,23 @@ def _dp_worker(rank, world, port, tmp):
     mom = 0.9 * 1.0 + 1.0                                   # momentum buffer after the two real updates
     assert torch.allclose(net.w.detach(), torch.full((4,), 0.5 - 0.5 * mom))
     assert guard.finish() == 0
+    # TWO flags in one step: torch's fused SGD skips only when found_inf == 1.0 exactly, so the guard must
+    # hand it 1.0, not the flags' sum -- an engine overflow together with a transport overflow leaves the weights alone
+    w_before = net.w.detach().clone()
+    one_step(engine_over=True, transport_grad=300.0)
+    assert float(guard.found) == 1.0 and torch.equal(net.w.detach(), w_before)
+    assert guard.finish() == 5 and guard.skipped == 3      # engine (1) + transport (4) flags of that step
+    # ... and a non-finite loss together with an engine overflow: skipped as well (it raises on the late read)
+    net.w.grad = torch.ones(4)
+    net._engines["e"].overflow.fill_(1)
+    guard.decide(torch.tensor(float("inf")))
+    opt.step()
+    assert float(guard.found) == 1.0 and torch.equal(net.w.detach(), w_before)
+    try:
+        guard.finish()
+        raise AssertionError("non-finite loss accepted")
+    except FloatingPointError:
+        pass
     try:
         one_step(loss=float("nan") if rank == 0 else 1.0)   # a non-finite loss on ONE rank raises on both, one step late
         guard.finish()

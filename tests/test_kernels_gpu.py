@@ -415,7 +415,8 @@ def test_split_forward_two_planes_equals_three(dev, B, H, W, C_, cout, k):
 
 def test_step_flags_kernel(dev):
     """mcamd_step_flags (train.StepGuard's device-side decision in one launch): [any engine overflow, loss not finite,
-    transport overflow], their sum for the fused SGD's found_inf, the int flags reset; and the found-only form used after
+    transport overflow], found_inf = EXACTLY 1.0 when any of them fired (torch's fused SGD tests `== 1`: a sum of two
+    flags, 2.0, would APPLY the update -- ADVICE r03), the int flags reset; and the found-only form used after
     the data-parallel MAX all-reduce of the flags."""
     for eng_vals, loss_v, t_v in (([0], 1.5, None), ([0, 7], 2.0, 0), ([0, 0], float("inf"), 1), ([3], float("nan"), None),
                                    ([], -1e30, 5), ([0], -float("inf"), 0)):
@@ -426,12 +427,12 @@ def test_step_flags_kernel(dev):
         found = torch.full((1,), 9.0, device=dev)
         ops.step_flags(eng, loss, tf, flags, found)
         want = [float(any(v != 0 for v in eng_vals)), float(not np.isfinite(loss_v)), float(bool(t_v))]
-        assert flags.tolist() == want and found.item() == sum(want), (eng_vals, loss_v, t_v, flags.tolist())
+        assert flags.tolist() == want and found.item() == float(any(want)), (eng_vals, loss_v, t_v, flags.tolist())
         assert all(int(e.item()) == 0 for e in eng) and (tf is None or int(tf.item()) == 0)
     flags = torch.tensor([1.0, 0.0, 1.0], device=dev)
     found = torch.zeros(1, device=dev)
     ops.step_flags([], None, None, flags, found)
-    assert flags.tolist() == [1.0, 0.0, 1.0] and found.item() == 2.0
+    assert flags.tolist() == [1.0, 0.0, 1.0] and found.item() == 1.0
 
 
 def test_pack_many_split_operands(dev):
