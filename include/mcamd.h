@@ -384,10 +384,27 @@ typedef struct mcamd_stem_block_desc {
                                              operands on this block (image and weights: 5.2e-4 -> 5.4e-4 on the logits,
                                              tools/error_budget.py) but hands its consumer an unrounded activation;
                                              2 = hi | lo in [dst_choff, dst_choff + 64) (consumer with x_wrap = 64) */
+    /* SPLIT OPERANDS (round 4; both NULL = plain fp16 operands): the reference multiplies fp32 by fp32 (F.conv2d,
+     * layers.py:60-64), and in TRAINING mode the operand rounding of this block alone moves the region-layer logits by
+     * 1.9e-2.  With x_lo = fp16(x - fp16(x)) in a second NHWC4 image (mcamd_nchw_f32_to_nhwc4_split) and wp_lo =
+     * fp16(w - fp16(w)) in the same packing as wp (mcamd_pack_stem_split) the pass accumulates
+     * x_hi w_hi + x_lo w_hi + x_hi w_lo in fp32.  Honoured by mcamd_stem_block_stats and by mcamd_stem_block_fwd with
+     * training == 0 (scale / shift read); the backward pass multiplies plain operands, as every backward pass does. */
+    const void* x_lo;
+    const void* wp_lo;
 } mcamd_stem_block_desc;
 size_t mcamd_stem_block_workspace_bytes(void);
+/* dst == NULL with training != 0: the statistics half only -- Gram sums, scale / shift / save_mean / save_invstd and the
+ * workspace context a later mcamd_stem_block_bwd reads; nothing is written to an output. */
 int mcamd_stem_block_fwd(const mcamd_stem_block_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 int mcamd_stem_block_bwd(const mcamd_stem_block_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+/* Batch statistics of the block's conv output WITHOUT storing it (the training-mode forward on split operands is two
+ * passes over the image: this one, mcamd_bn_coeffs on its slab, then mcamd_stem_block_fwd with training == 0):
+ * stats[row][0][c] = sum over the pixels of workgroup `row` of y[.][c], stats[row][1][c] = sum of squares, fp32
+ * [mcamd_stem_block_stats_rows(d)][2][stats_ld >= 32], every row written, fixed order (deterministic) -- the slab
+ * mcamd_bn_coeffs takes, as mcamd_conv_epilogue.stats.  nn.BatchNorm2d's batch statistics (src/nets.py:802). */
+int32_t mcamd_stem_block_stats_rows(const mcamd_stem_block_desc* d);
+int mcamd_stem_block_stats(const mcamd_stem_block_desc* d, float* stats, int32_t stats_rows, int32_t stats_ld, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Layout conversion at the model boundary (Darknet.forward takes/returns NCHW fp32,
@@ -407,6 +424,14 @@ int mcamd_nchw_f32_to_padded_nhwc_f16_pad(const float* src, int32_t B, int32_t C
  * input of the "fp16x3" / "mixed" precision modes (nets.py:720 takes the image as fp32 NCHW). */
 int mcamd_nchw_f32_to_padded_nhwc_f16_split(const float* src, int32_t B, int32_t C, int32_t H, int32_t W,
                                             void* dst, int32_t dst_ld, int32_t dst_choff, int32_t plane, void* stream);
+
+/* The image for the split-operand first block (mcamd_stem_block_desc.x / x_lo): src fp32 [B][3][H][W] -> two padded
+ * NHWC4 fp16 images [B][H+2][W+2][4], hi = fp16(v) and lo = fp16(v - hi), channel 3 zero; the halo is not written
+ * (zero it once).  nets.py:720 takes the image as fp32 NCHW. */
+int mcamd_nchw_f32_to_nhwc4_split(const float* src, int32_t B, int32_t H, int32_t W, void* hi, void* lo, void* stream);
+/* The stem packing of mcamd_pack_weights (g->stem) for split operands: wp_hi = fp16(w * mask), wp_lo =
+ * fp16(w * mask - wp_hi), both [Npad][96]. */
+int mcamd_pack_stem_split(const float* w_oihw, const float* mask_oihw, int32_t cout, void* wp_hi, void* wp_lo, void* stream);
 
 /* The first convolution of the split-operand precisions in fp32 on the vector ALUs, straight from the image
  * (F.conv2d(x, weight * mask, None, 1, 1) at layers.py:60-64 for a 3-channel input, 3x3 kernel, 32 filters):

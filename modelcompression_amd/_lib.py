@@ -79,7 +79,8 @@ class StemBlockDesc(C.Structure):
                 ("dst", C.c_void_p), ("dst_ld", C.c_int32), ("dst_choff", C.c_int32),
                 ("g", C.c_void_p), ("g_ld", C.c_int32), ("g_choff", C.c_int32),
                 ("mask", C.c_void_p), ("grad_scale", C.c_float),
-                ("dw", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("cout", C.c_int32), ("planes", C.c_int32)]
+                ("dw", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("cout", C.c_int32), ("planes", C.c_int32),
+                ("x_lo", C.c_void_p), ("wp_lo", C.c_void_p)]
 
 
 class RegionDesc(C.Structure):
@@ -126,6 +127,10 @@ SIGNATURES = {
     "mcamd_stem_block_workspace_bytes": (_SZ, []),
     "mcamd_stem_block_fwd": (C.c_int, [C.POINTER(StemBlockDesc), _P, _SZ, _P]),
     "mcamd_stem_block_bwd": (C.c_int, [C.POINTER(StemBlockDesc), _P, _SZ, _P]),
+    "mcamd_stem_block_stats_rows": (_I32, [C.POINTER(StemBlockDesc)]),
+    "mcamd_stem_block_stats": (C.c_int, [C.POINTER(StemBlockDesc), _P, _I32, _I32, _P]),
+    "mcamd_nchw_f32_to_nhwc4_split": (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _P]),
+    "mcamd_pack_stem_split": (C.c_int, [_P, _P, _I32, _P, _P, _P]),
     "mcamd_nchw_f32_to_padded_nhwc_f16": (C.c_int, [_P, _I32, _I32, _I32, _I32, _F, _P, _I32, _I32, _P, _P]),
     "mcamd_nchw_f32_to_padded_nhwc_f16_pad": (C.c_int, [_P, _I32, _I32, _I32, _I32, _F, _P, _I32, _I32, _I32, _P, _P]),
     "mcamd_nchw_f32_to_padded_nhwc_f16_split": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _P]),

@@ -105,9 +105,10 @@ __host__ __device__ __forceinline__ int kpos(int t, int c, int taps, int chp) {
     return (c / kb) * taps * kb + t * kb + c % kb;
 }
 
+// `wlo` (may be NULL): the residual fp16(v - fp16(v)) of every entry in the same layout -- the lo half of split operands
 __global__ __launch_bounds__(256) void pack_fwd_kernel(const float* w, const float* mask, half_t* wp, int Cout, int Cin,
                                                        int ks, int cin_tap, int stem, long long total, int ktot,
-                                                       const int* rmap, const int* cmap) {
+                                                       const int* rmap, const int* cmap, half_t* wlo = nullptr) {
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         int n = (int)(idx / ktot);
         int k = (int)(idx - (long long)n * ktot);
@@ -137,7 +138,9 @@ __global__ __launch_bounds__(256) void pack_fwd_kernel(const float* w, const flo
                 if (mask) v *= mask[src];
             }
         }
-        wp[idx] = (half_t)v;
+        const half_t hv = (half_t)v;
+        wp[idx] = hv;
+        if (wlo) wlo[idx] = (half_t)(v - (float)hv);
     }
 }
 
@@ -196,6 +199,23 @@ extern "C" int mcamd_pack_weights(const mcamd_conv_geom* g, const float* w_oihw,
                            g->cout, g->cin, g->ksize, cout_p_of(g), total, ktot, rmap, cmap);
     }
     MCAMD_LAUNCH_CHECK("pack_weights");
+    return MCAMD_OK;
+}
+
+extern "C" int mcamd_pack_stem_split(const float* w_oihw, const float* mask_oihw, int32_t cout, void* wp_hi, void* wp_lo,
+                                     void* stream) {
+    if (mcamd_recording())
+        return mcamd_rec_push(stream, [=](void* s) { return mcamd_pack_stem_split(w_oihw, mask_oihw, cout, wp_hi, wp_lo, s); });
+    MCAMD_REQUIRE(w_oihw && wp_hi && wp_lo && cout > 0, "pack_stem_split: bad argument");
+    mcamd_conv_geom g = {};
+    g.B = 1, g.H = 2, g.W = 32, g.ksize = 3, g.cin = 3, g.cout = cout, g.x_ld = 4, g.stem = 1;
+    const int ktot = ntaps_of(&g) * cin_tap_of(&g);
+    const long long total = mcamd_packed_elems_fwd(&g);
+    long long grid = (total + 256 * 4 - 1) / (256 * 4);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(pack_fwd_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, w_oihw, mask_oihw, (half_t*)wp_hi,
+                       cout, 3, 3, cin_tap_of(&g), 1, total, ktot, (const int*)nullptr, (const int*)nullptr, (half_t*)wp_lo);
+    MCAMD_LAUNCH_CHECK("pack_stem_split");
     return MCAMD_OK;
 }
 
@@ -386,7 +406,7 @@ static int fill_epilogue(IgemmArgs& a, const mcamd_conv_epilogue* e, int n_out, 
                       "%s: fp32 output slice [%d, %d) does not fit y_ld %d", what, e->y_choff, e->y_choff + n_out, e->y_ld);
         if (e->stats) {
             // the fp32 epilogue lives in the LDS-staged implicit-GEMM kernels only (mcamd_conv_stats_rows_mode)
-            int rows = mcamd_igemm_rows(M, n_out, cin_tap, ktot, false);
+            int rows = expected_rows >= 0 ? expected_rows : mcamd_igemm_rows(M, n_out, cin_tap, ktot, false);
             MCAMD_REQUIRE(e->stats_rows == rows, "%s: stats_rows must be mcamd_conv_stats_rows_mode(g, 3) = %d (got %d)", what,
                           rows, e->stats_rows);
             MCAMD_REQUIRE(e->stats_ld >= round_up_int(n_out, 256), "%s: stats_ld must be >= %d", what,
@@ -410,8 +430,12 @@ extern "C" int32_t mcamd_conv_stats_rows(const mcamd_conv_geom* g) {
 
 extern "C" int32_t mcamd_conv_stats_rows_mode(const mcamd_conv_geom* g, int32_t mode) {
     if (!g) return 0;
-    if (mode == MCAMD_EPI_RAW_F32)
+    if (mode == MCAMD_EPI_RAW_F32) {
+        if (g->pad == 0 && mcamd_small3x3_split_ok((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g), ntaps_of(g) * cin_tap_of(g),
+                                                   g->x_wrap, mode))
+            return mcamd_small3x3_rows((long long)g->B * g->H * g->W);
         return mcamd_igemm_rows((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g), ntaps_of(g) * cin_tap_of(g), false);
+    }
     return mcamd_conv_stats_rows(g);
 }
 
@@ -469,9 +493,13 @@ extern "C" int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const voi
     const bool stem_direct = epi && mcamd_stem_direct_ok(g->stem, g->cout, epi->mode);
     const bool wres = epi && epi->dst_mode == MCAMD_DST_PLAIN && g->pad == 0 &&
                       mcamd_wres_ok(g->ksize, g->stem, g->cout, a.cin_tap, a.ktot, g->B, g->H, g->W, epi->mode);
+    const bool small_split = epi && g->pad == 0 && !g->stem && g->x_choff == 0 &&
+                             mcamd_small3x3_split_ok(a.M, g->cout, a.cin_tap, a.ktot, g->x_wrap, epi->mode);
     if (fill_epilogue(a, epi, g->cout, a.M, a.cin_tap, a.ktot, "conv_fwd",
-                      stem_direct ? mcamd_stem_rows(a.M) : (wres ? mcamd_wres_rows(g->cout, g->B, g->H, g->W) : -1)))
+                      stem_direct ? mcamd_stem_rows(a.M) : (wres ? mcamd_wres_rows(g->cout, g->B, g->H, g->W)
+                                                                 : (small_split ? mcamd_small3x3_rows(a.M) : -1))))
         return MCAMD_EINVAL;
+    if (small_split) return mcamd_small3x3_split_launch(a, (hipStream_t)stream);   // conv_small.hip: weights resident, split operands
     if (wres) return mcamd_wres_launch(a, g->B, (hipStream_t)stream);
     if (stem_direct) {       // conv_stem.hip: weights in registers, image fragments straight from global memory
         StemArgs q;

@@ -34,6 +34,10 @@ namespace {
 struct StemBlockArgs {
     const half_t* x;        // padded NHWC4 image, pixel (0, 0, 0)
     const half_t* w;        // packed stem weights [>= 32][96], k = ty*32 + tx*4 + c
+    const half_t* xl;       // split operands: lo image, fp16(x - fp16(x)), same layout (NULL = plain operands)
+    const half_t* wl;       // split operands: lo weights, fp16(w - fp16(w)), same packing
+    float* stats;           // stats pass: fp32 [gridDim.x][2][stats_ld] per-channel sums / sums of squares of y
+    int stats_ld;
     const float* scale;     // [32]
     const float* shift;     // [32]
     half_t* out;            // pooled output, padded NHWC pixel (0, 0, 0)
@@ -284,16 +288,22 @@ __global__ __launch_bounds__(1024) void stem_coeffs_kernel(const double* csum, c
 // 16-byte pieces (1 KB contiguous when dst_ld == 32).
 __device__ __forceinline__ int pooled_of(int q, int kg) { return (q & 1) + 4 * (q >> 1) + 2 * kg; }   // pooled pixel of register pair q
 
-template <int UN, int PL>   // PL = 3: split (hi | lo | hi) storage of the pooled output (32 channels per plane, adjacent planes)
+// SPLIT: the convolution on split operands, y = x_hi w_hi + x_lo w_hi + x_hi w_lo in the fp32 accumulators (three MFMAs
+// per product; the dropped x_lo w_lo term is 2^-22): the first block of the "mixed" TRAINING precision, whose operand
+// rounding alone would cost 1.9e-2 on the train-mode logits (engine.py MIXED_BUDGET_TRAIN).  The pass stays HBM-bound.
+template <int UN, int PL, bool SPLIT = false>   // PL = 3: split (hi | lo | hi) storage of the pooled output (32 channels per plane, adjacent planes)
 __global__ __launch_bounds__(256) void stem_block_fwd_kernel(StemBlockArgs a) {
     constexpr int TW = 32 * PL;                       // halfs per pooled pixel in the tile
     __shared__ __attribute__((aligned(16))) half_t tile[4][16 * TW];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 31, kg = lane >> 5;
-    h8_t wf[3];
+    h8_t wf[3], wlo[SPLIT ? 3 : 1];
 #pragma unroll
-    for (int ty = 0; ty < 3; ++ty) wf[ty] = *(const h8_t*)(a.w + (long long)pl * 96 + ty * 32 + 8 * kg);
+    for (int ty = 0; ty < 3; ++ty) {
+        wf[ty] = *(const h8_t*)(a.w + (long long)pl * 96 + ty * 32 + 8 * kg);
+        if (SPLIT) wlo[ty] = *(const h8_t*)(a.wl + (long long)pl * 96 + ty * 32 + 8 * kg);
+    }
     const float sc = pl < a.cout ? a.scale[pl] : 0.f, sh = pl < a.cout ? a.shift[pl] : 0.f;   // slim models: fewer than 32 filters
     half_t* tw = tile[wave];
     const int nunits = (int)a.nunits;
@@ -303,18 +313,26 @@ __global__ __launch_bounds__(256) void stem_block_fwd_kernel(StemBlockArgs a) {
     const UnitPos dstep = unit_decode(wstride - (UN - 1), a.Wb, a.H2), one = {0, 1, 0};
     const unsigned row_elems = (a.W + 2) * 4, lane_off = (pl + 2 * kg) * 4;
     for (; u0 < nunits; u0 += wstride) {
-        h8_t xr[UN][4];
+        h8_t xr[UN][4], xlo[SPLIT ? UN : 1][4];
         int ub[UN], uh[UN], uw[UN];
 #pragma unroll
         for (int i = 0; i < UN; ++i) {
             ub[i] = pos.b, uh[i] = pos.h, uw[i] = pos.w;
-            const half_t* xb = a.x + uniform_off(((long long)(pos.b * (a.H + 2) + 2 * pos.h) * (a.W + 2) + pos.w * 32) * 4);
+            const long long xoff = uniform_off(((long long)(pos.b * (a.H + 2) + 2 * pos.h) * (a.W + 2) + pos.w * 32) * 4);
+            const half_t* xb = a.x + xoff;
             if (u0 + i < nunits) {
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) xr[i][rr] = *(const h8_t*)((const char*)xb + (lane_off + rr * row_elems) * 2u);
+                if (SPLIT) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) xlo[i][rr] = *(const h8_t*)((const char*)(a.xl + xoff) + (lane_off + rr * row_elems) * 2u);
+                }
             } else {
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) xr[i][rr] = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                for (int rr = 0; rr < 4; ++rr) {
+                    xr[i][rr] = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                    if (SPLIT) xlo[i][rr] = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                }
             }
             if (i + 1 < UN) unit_advance(pos, one, a.Wb, a.H2);
         }
@@ -324,6 +342,15 @@ __global__ __launch_bounds__(256) void stem_block_fwd_kernel(StemBlockArgs a) {
             f32x16_t acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+            if (SPLIT) {     // the small terms first, so that the large products round last
+#pragma unroll
+                for (int ty = 0; ty < 3; ++ty) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xlo[i][ty], wf[ty], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xlo[i][ty + 1], wf[ty], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xr[i][ty], wlo[ty], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xr[i][ty + 1], wlo[ty], acc1, 0, 0, 0);
+                }
+            }
 #pragma unroll
             for (int ty = 0; ty < 3; ++ty) {
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xr[i][ty], wf[ty], acc0, 0, 0, 0);
@@ -352,6 +379,95 @@ __global__ __launch_bounds__(256) void stem_block_fwd_kernel(StemBlockArgs a) {
                              a.out_choff + pc * 8) = v;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Statistics pass of the split-operand first block: the same units and the same accumulators as the forward pass, but
+// nothing is written except per-channel sums and sums of squares of the fp32 conv output (a lane is a channel, its
+// registers are pixels: the sums are plain register adds).  One slab row per workgroup, mcamd_bn_coeffs finishes them in
+// double as it does for every other block -- batch statistics of the UNROUNDED y, as the reference forms them
+// (nn.BatchNorm2d on the fp32 conv output, src/nets.py:802).  The Gram route of the plain-operand block is exact for the
+// fp16-rounded image only; a real 8-bit image has a deterministic rounding error per grey level, which need not average out.
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void stem_block_stats_kernel(StemBlockArgs a) {
+    constexpr int UN = 2;
+    __shared__ float red[4][2][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 31, kg = lane >> 5;
+    h8_t wf[3], wlo[SPLIT ? 3 : 1];
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+        wf[ty] = *(const h8_t*)(a.w + (long long)pl * 96 + ty * 32 + 8 * kg);
+        if (SPLIT) wlo[ty] = *(const h8_t*)(a.wl + (long long)pl * 96 + ty * 32 + 8 * kg);
+    }
+    float s1 = 0.f, s2 = 0.f;
+    const int nunits = (int)a.nunits;
+    const int wstride = gridDim.x * 4 * UN;
+    int u0 = (blockIdx.x * 4 + wave) * UN;
+    UnitPos pos = unit_decode(u0 < nunits ? u0 : 0, a.Wb, a.H2);
+    const UnitPos dstep = unit_decode(wstride - (UN - 1), a.Wb, a.H2), one = {0, 1, 0};
+    const unsigned row_elems = (a.W + 2) * 4, lane_off = (pl + 2 * kg) * 4;
+    for (; u0 < nunits; u0 += wstride) {
+        h8_t xr[UN][4], xlo[SPLIT ? UN : 1][4];
+#pragma unroll
+        for (int i = 0; i < UN; ++i) {
+            const long long xoff = uniform_off(((long long)(pos.b * (a.H + 2) + 2 * pos.h) * (a.W + 2) + pos.w * 32) * 4);
+            if (u0 + i < nunits) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    xr[i][rr] = *(const h8_t*)((const char*)(a.x + xoff) + (lane_off + rr * row_elems) * 2u);
+                    if (SPLIT) xlo[i][rr] = *(const h8_t*)((const char*)(a.xl + xoff) + (lane_off + rr * row_elems) * 2u);
+                }
+            } else {        // (zero operands: y = 0 adds nothing to either sum)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    xr[i][rr] = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                    if (SPLIT) xlo[i][rr] = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                }
+            }
+            if (i + 1 < UN) unit_advance(pos, one, a.Wb, a.H2);
+        }
+        unit_advance(pos, dstep, a.Wb, a.H2);
+#pragma unroll
+        for (int i = 0; i < UN; ++i) {
+            f32x16_t acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+            if (SPLIT) {
+#pragma unroll
+                for (int ty = 0; ty < 3; ++ty) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xlo[i][ty], wf[ty], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xlo[i][ty + 1], wf[ty], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xr[i][ty], wlo[ty], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xr[i][ty + 1], wlo[ty], acc1, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xr[i][ty], wf[ty], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xr[i][ty + 1], wf[ty], acc1, 0, 0, 0);
+            }
+            // the unit's 32 values of this lane first (short chains), then onto the running sums
+            float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                u1 += acc0[r] + acc1[r];
+                u2 = __builtin_fmaf(acc0[r], acc0[r], u2);
+                u2 = __builtin_fmaf(acc1[r], acc1[r], u2);
+            }
+            s1 += u1, s2 += u2;
+        }
+    }
+    red[wave][0][lane] = s1, red[wave][1][lane] = s2;
+    __syncthreads();
+    if (tid < 64) {           // fixed order: waves 0..3, pixel halves kg = 0, 1
+        const int which = tid >> 5, ch = tid & 31;
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) v += red[wv][which][ch] + red[wv][which][32 + ch];
+        a.stats[((long long)blockIdx.x * 2 + which) * a.stats_ld + ch] = v;
     }
 }
 
@@ -572,6 +688,37 @@ void fill_args(StemBlockArgs& a, const mcamd_stem_block_desc* d) {
     a.B = d->B, a.H = d->H, a.W = d->W, a.H2 = d->H / 2, a.W2 = d->W / 2, a.Wb = d->W / 32;
     a.slope = d->slope;
     a.cout = d->cout > 0 ? d->cout : 32;
+    a.xl = (const half_t*)d->x_lo;
+    a.wl = (const half_t*)d->wp_lo;
+}
+
+// fp32 NCHW image -> two padded NHWC4 fp16 images: hi = fp16(v), lo = fp16(v - hi) (channel 3 zero in both).
+// Consecutive threads take consecutive pixels: three coalesced plane reads, one 8-byte store per image.
+__global__ __launch_bounds__(256) void nhwc4_split_kernel(const float* src, int B, int H, int W, half_t* hi, half_t* lo) {
+    const int HW = H * W;
+    const long long total = (long long)B * HW;
+    for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (long long)gridDim.x * 256) {
+        const int b = (int)(pix / HW), rem = (int)(pix - (long long)b * HW);
+        const int h = rem / W, w = rem - h * W;
+        const float* sp = src + (long long)b * 3 * HW + rem;
+        h4_t vh, vl;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = fminf(fmaxf(sp[(long long)c * HW], -65504.f), 65504.f);
+            vh[c] = (half_t)v;
+            vl[c] = (half_t)(v - (float)vh[c]);
+        }
+        vh[3] = vl[3] = (half_t)0.f;
+        const long long o = (((long long)b * (H + 2) + h + 1) * (W + 2) + w + 1) * 4;
+        *(h4_t*)(hi + o) = vh;
+        *(h4_t*)(lo + o) = vl;
+    }
+}
+
+int stats_grid(const mcamd_stem_block_desc* d) {
+    const long long nunits = (long long)d->B * (d->H / 2) * (d->W / 32);
+    const long long want = (nunits + 7) / 8;      // >= one pass of 2 units per wave
+    return (int)(want < 1024 ? (want < 1 ? 1 : want) : 1024);
 }
 
 }  // namespace
@@ -587,7 +734,14 @@ extern "C" int mcamd_stem_block_fwd(const mcamd_stem_block_desc* d, void* worksp
     if (check_desc(d, "stem_block_fwd")) return MCAMD_EINVAL;
     MCAMD_REQUIRE(d->planes >= 0 && d->planes <= 3, "stem_block_fwd: planes must be 1, 2 or 3 (got %d)", d->planes);
     const int span = d->planes >= 2 ? 32 * d->planes : 32;
-    MCAMD_REQUIRE(d->dst && d->dst_ld % 8 == 0 && d->dst_choff % 8 == 0 && d->dst_choff + span <= d->dst_ld,
+    const bool split = d->x_lo != nullptr || d->wp_lo != nullptr;
+    MCAMD_REQUIRE(!split || (d->x_lo && d->wp_lo), "stem_block_fwd: split operands need both x_lo and wp_lo");
+    MCAMD_REQUIRE(!split || (!d->training && (d->cout == 0 || d->cout == 32)),
+                  "stem_block_fwd: split operands take scale / shift from mcamd_stem_block_stats + mcamd_bn_coeffs (training must "
+                  "be 0) and 32 filters");
+    // dst == NULL with training != 0: statistics only (Gram sums, coefficients and the context the backward pass reads)
+    MCAMD_REQUIRE(d->dst || d->training, "stem_block_fwd: null dst (allowed with training != 0 only: statistics, no output)");
+    MCAMD_REQUIRE(!d->dst || (d->dst_ld % 8 == 0 && d->dst_choff % 8 == 0 && d->dst_choff + span <= d->dst_ld),
                   "stem_block_fwd: output slice [%d, %d) does not fit dst_ld %d", d->dst_choff, d->dst_choff + span, d->dst_ld);
     const Carve c = carve();
     hipStream_t st = (hipStream_t)stream;
@@ -616,18 +770,70 @@ extern "C" int mcamd_stem_block_fwd(const mcamd_stem_block_desc* d, void* worksp
                            d->scale, d->shift, d->save_mean, d->save_invstd, (double*)(ws + c.ctx));
         MCAMD_LAUNCH_CHECK("stem_coeffs");
     }
+    if (!d->dst) return MCAMD_OK;
     a.out = (half_t*)d->dst;
     a.out_ld = d->dst_ld, a.out_choff = d->dst_choff;
     a.nunits = (long long)d->B * a.H2 * a.Wb;
     long long want = (a.nunits + 7) / 8;          // >= one pass of 2 units per wave
     const int grid = (int)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
     const int un = MCAMD_ENV_INT("MCAMD_STEM_FWD_UN", 4);   // tuning switch
-    if (d->planes == 3) hipLaunchKernelGGL((stem_block_fwd_kernel<2, 3>), dim3(grid), dim3(256), 0, st, a);
+    if (split) {
+        if (d->planes == 3) hipLaunchKernelGGL((stem_block_fwd_kernel<2, 3, true>), dim3(grid), dim3(256), 0, st, a);
+        else if (d->planes == 2) hipLaunchKernelGGL((stem_block_fwd_kernel<2, 2, true>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((stem_block_fwd_kernel<2, 1, true>), dim3(grid), dim3(256), 0, st, a);
+    } else if (d->planes == 3) hipLaunchKernelGGL((stem_block_fwd_kernel<2, 3>), dim3(grid), dim3(256), 0, st, a);
     else if (d->planes == 2) hipLaunchKernelGGL((stem_block_fwd_kernel<2, 2>), dim3(grid), dim3(256), 0, st, a);
     else if (un == 4) hipLaunchKernelGGL((stem_block_fwd_kernel<4, 1>), dim3(grid), dim3(256), 0, st, a);
     else if (un == 1) hipLaunchKernelGGL((stem_block_fwd_kernel<1, 1>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((stem_block_fwd_kernel<2, 1>), dim3(grid), dim3(256), 0, st, a);
     MCAMD_LAUNCH_CHECK("stem_block_fwd");
+    return MCAMD_OK;
+}
+
+extern "C" int mcamd_nchw_f32_to_nhwc4_split(const float* src, int32_t B, int32_t H, int32_t W, void* hi, void* lo, void* stream) {
+    if (mcamd_recording())
+        return mcamd_rec_push(stream, [=](void* s) { return mcamd_nchw_f32_to_nhwc4_split(src, B, H, W, hi, lo, s); });
+    MCAMD_REQUIRE(src && hi && lo && B > 0 && H > 0 && W > 0, "nchw_to_nhwc4_split: bad argument");
+    MCAMD_REQUIRE((long long)B * H * W < (1ll << 31), "nchw_to_nhwc4_split: more than 2^31 pixels");
+    const long long total = (long long)B * H * W;
+    long long grid = (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(nhwc4_split_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, src, B, H, W, (half_t*)hi, (half_t*)lo);
+    MCAMD_LAUNCH_CHECK("nchw_to_nhwc4_split");
+    return MCAMD_OK;
+}
+
+extern "C" int32_t mcamd_stem_block_stats_rows(const mcamd_stem_block_desc* d) {
+    if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0) return 0;
+    return stats_grid(d);
+}
+
+extern "C" int mcamd_stem_block_stats(const mcamd_stem_block_desc* d, float* stats, int32_t stats_rows, int32_t stats_ld,
+                                      void* stream) {
+    if (mcamd_recording()) {
+        MCAMD_REQUIRE(d, "stem_block_stats: null descriptor");
+        const mcamd_stem_block_desc d_ = *d;
+        return mcamd_rec_push(stream, [=](void* s) { return mcamd_stem_block_stats(&d_, stats, stats_rows, stats_ld, s); });
+    }
+    MCAMD_REQUIRE(d, "stem_block_stats: null descriptor");
+    MCAMD_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0, "stem_block_stats: non-positive dimension");
+    MCAMD_REQUIRE(d->W % 32 == 0 && d->H % 2 == 0, "stem_block_stats: needs W %% 32 == 0 and an even H (got %d x %d)", d->H, d->W);
+    MCAMD_REQUIRE((long long)d->B * d->H * d->W < (1ll << 31), "stem_block_stats: more than 2^31 output pixels");
+    MCAMD_REQUIRE(d->x && d->wp && stats, "stem_block_stats: null argument");
+    MCAMD_REQUIRE(d->cout == 0 || d->cout == 32, "stem_block_stats: 32 filters (got %d)", d->cout);
+    const bool split = d->x_lo != nullptr || d->wp_lo != nullptr;
+    MCAMD_REQUIRE(!split || (d->x_lo && d->wp_lo), "stem_block_stats: split operands need both x_lo and wp_lo");
+    const int grid = stats_grid(d);
+    MCAMD_REQUIRE(stats_rows == grid && stats_ld >= 32, "stem_block_stats: slab must be [%d][2][>= 32] (got %d rows, ld %d)",
+                  grid, stats_rows, stats_ld);
+    StemBlockArgs a;
+    fill_args(a, d);
+    a.nunits = (long long)d->B * a.H2 * a.Wb;
+    a.stats = stats, a.stats_ld = stats_ld;
+    hipStream_t st = (hipStream_t)stream;
+    if (split) hipLaunchKernelGGL((stem_block_stats_kernel<true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((stem_block_stats_kernel<false>), dim3(grid), dim3(256), 0, st, a);
+    MCAMD_LAUNCH_CHECK("stem_block_stats");
     return MCAMD_OK;
 }
 

@@ -100,6 +100,8 @@ int mcamd_win3x3_launch(const IgemmArgs& a, hipStream_t st);
 bool mcamd_small3x3_ok(long long M, int n, int cin_tap, int ktot);   // conv_small.hip
 int mcamd_small3x3_rows(long long M);
 int mcamd_small3x3_launch(const IgemmArgs& a, hipStream_t st);
+bool mcamd_small3x3_split_ok(long long M, int n, int cin_tap, int ktot, int wrap, int mode);   // split operands, fp32 output
+int mcamd_small3x3_split_launch(const IgemmArgs& a, hipStream_t st);
 
 bool mcamd_wres_ok(int ksize, int stem, int n, int cin_tap, int ktot, int B, int H, int W, int mode);   // conv_wres.hip
 int mcamd_wres_rows(int n, int B, int H, int W);

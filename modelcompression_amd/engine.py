@@ -22,6 +22,7 @@ batch size; a B=64 training step holds ~7 GB of the 288 GB.
 """
 import contextlib
 import os
+import time
 
 import torch
 
@@ -417,11 +418,21 @@ class Engine:
                                        and os.environ.get("MCAMD_STEM_FUSED", "1") == "1")
             lay.stem_shadow = bool(li_is_first(lay) and self.stem_shadow and lay.bn is not None and lay.mode == L.DST_POOL
                                    and lay.out2_id is None and lay.cout == 32 and lay.border is None)
+            # ... and (round 4) its FORWARD pass is the fused first block too, on SPLIT operands: a statistics pass over the
+            # hi / lo NHWC4 images that writes nothing but per-channel sums, then conv + BatchNorm + LeakyReLU + MaxPool
+            # recomputed and written once as the pooled hi | lo planes (csrc/conv_stem_block.hip, SPLIT).  Replaces the fp32
+            # first convolution's 1.4 GB raw output, its BatchNorm pass and the scratch forward of the plain block:
+            # 1.16 -> ~0.3 ms per B=64 step.  MCAMD_STEM_SPLIT=0: the round-3 path.
+            lay.stem_split = bool(lay.stem_shadow and os.environ.get("MCAMD_STEM_SPLIT", "1") == "1")
             if lay.stem_shadow:
                 lay.sh_img = ops.alloc_padded(B, lay.H, lay.W, 4, dev)                    # NHWC4 fp16 image
                 lay.sh_geom = ops.geom(B, lay.H, lay.W, 3, 3, lay.cout, 4, 0, 1)
                 lay.sh_wp = torch.zeros(ops.packed_elems(lay.sh_geom)[0], dtype=ops.HALF, device=dev)
-                lay.sh_dst = ops.alloc_padded(B, lay.H // 2, lay.W // 2, 32, dev)          # scratch pooled output
+                if lay.stem_split:
+                    lay.sh_img_lo = ops.alloc_padded(B, lay.H, lay.W, 4, dev)             # fp16(x - fp16(x))
+                    lay.sh_wp_lo = torch.zeros_like(lay.sh_wp)
+                else:
+                    lay.sh_dst = ops.alloc_padded(B, lay.H // 2, lay.W // 2, 32, dev)      # scratch pooled output
                 lay.sh_coef = [torch.empty(lay.cout, **f32) for _ in range(4)]             # scale, shift, mean, invstd
                 lay.stem_ws = torch.empty(ops.stem_block_workspace_bytes(), dtype=torch.uint8, device=dev)
             lay.dy = None if (lay.fused_stem or lay.stem_shadow) else ops.alloc_padded(B, lay.H, lay.W, lay.cout_p, dev, pad=lay.pad)
@@ -441,10 +452,15 @@ class Engine:
                     # (csrc/conv_stem_f32.hip) instead of hi | lo | hi image planes through the generic MFMA kernel
                     # (layout 0.38 + conv 0.86 ms per B=64 step -> 0.4 ms, and exact fp32 products).
                     lay.stem_f32 = bool(self.precise and li_is_first(lay) and lay.cin == 3 and lay.k == 3 and lay.cout == 32
-                                        and lay.bn is not None and os.environ.get("MCAMD_STEM_F32", "1") == "1")
+                                        and lay.bn is not None and not lay.stem_split
+                                        and os.environ.get("MCAMD_STEM_F32", "1") == "1")
                     # zero-initialised: with filter compaction the convolution writes the kept channels only
-                    lay.y = torch.zeros(lay.M * lay.cout, dtype=torch.float32 if self.precise else ops.HALF, device=dev)
-                    if lay.stem_f32:
+                    # (the split-operand fused first block never stores its raw output)
+                    lay.y = None if lay.stem_split else torch.zeros(lay.M * lay.cout, dtype=torch.float32 if self.precise else ops.HALF,
+                                                                    device=dev)
+                    if lay.stem_split:
+                        lay.stats = torch.zeros(ops.stem_block_stats_rows(B, lay.H, lay.W), 2, ops.round_up(lay.cout, 256), **f32)
+                    elif lay.stem_f32:
                         lay.stats = torch.zeros(ops.stem_conv_f32_stats_rows(), 2, ops.round_up(lay.cout, 256), **f32)
                         lay.weff = torch.empty(lay.cout * 27, **f32)
                     else:
@@ -513,11 +529,22 @@ class Engine:
         """Run one library call; when profiling, bracket it with HIP events on the launch stream."""
         if self.events is None:
             return fn(*args, **kw)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # (events come from a pool the caller may hand in -- `self.event_pool`, a list of reusable timing events -- so that a
+        # long instrumented pass does not keep hundreds of profiling signals alive; the host-side seconds of the three
+        # parts [record, call, record] are kept next to the pair: a GPU-side gap with a long host part is a HOST stall)
+        pool = getattr(self, "event_pool", None)
+        if pool:
+            e0, e1 = pool.pop(), pool.pop()
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
         e0.record()
+        t1 = time.perf_counter()
         r = fn(*args, **kw)
+        t2 = time.perf_counter()
         e1.record()
-        self.events.append((tag, lay, e0, e1))
+        t3 = time.perf_counter()
+        self.events.append((tag, lay, e0, e1, (t1 - t0, t2 - t1, t3 - t2)))
         return r
 
     def conv_flops(self, lay):
@@ -658,7 +685,9 @@ class Engine:
             mask = lay.conv.mask if lay.conv.mask_flag else None
             if lay.stem:
                 ops.pack_weights(lay.geom_f, lay.conv.weight.data, mask, True, False, lay.wp, None)
-            if getattr(lay, "stem_shadow", False):
+            if getattr(lay, "stem_split", False):
+                ops.pack_stem_split(lay.conv.weight.data, mask, lay.sh_wp, lay.sh_wp_lo)
+            elif getattr(lay, "stem_shadow", False):
                 ops.pack_weights(lay.sh_geom, lay.conv.weight.data, mask, True, False, lay.sh_wp, None)
 
     # ------------------------------------------------------------------ filter compaction
@@ -843,7 +872,9 @@ class Engine:
         xs = x.detach().contiguous().float()
         if self.precise and not self.stem:
             l0 = self.layers[0]
-            if l0.stem_f32:
+            if l0.stem_split:
+                ops.nchw_to_nhwc4_split(xs, l0.sh_img, l0.sh_img_lo)      # hi and lo NHWC4 images in one pass
+            elif l0.stem_f32:
                 # the first convolution in fp32 from the image itself (outside the recorded plan: the image pointer is
                 # the caller's); the hi plane of the image is still needed where the generic weight gradient reads it
                 if training and not l0.stem_shadow:
@@ -856,7 +887,7 @@ class Engine:
                 # (written by the layout kernel itself: round 2 built the planes with torch.cat, three 3 x B x H x W fp32
                 # temporaries per forward -- 0.8 GB at B=128 through the caching allocator)
                 ops.nchw_to_padded_split(xs, self.bufs[tin.buf], tin.ld, tin.choff, tin.ps)
-            if training and l0.stem_shadow:
+            if training and l0.stem_shadow and not l0.stem_split:
                 ops.nchw_to_padded(xs, l0.sh_img, 4, 0)
         else:
             ops.nchw_to_padded(xs, self.bufs[tin.buf], tin.ld, tin.choff)
@@ -912,6 +943,15 @@ class Engine:
                             momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps, cout=lay.cout,
                             planes=self.act_planes)
                 continue
+            if training and lay.stem_split:
+                # statistics half of the plain-operand block (dst None): Gram context + self-consistent coefficients for the
+                # backward pass (no running-statistics update: the split pass below owns them)
+                c = lay.sh_coef
+                ops.stem_block_fwd(B, lay.H, lay.W, lay.sh_img, lay.sh_wp, bn.weight.data, bn.bias.data, None, None, True,
+                                   c[0], c[1], c[2], c[3], lay.slope, None, 0, 0, lay.stem_ws,
+                                   momentum=0.0, eps=bn.eps, cout=lay.cout, planes=1)
+                self._timed('fwd', lay, self._stem_split_forward, lay)
+                continue
             if training and lay.stem_shadow:
                 # the fused first block on plain operands into a scratch output: fills the workspace and the coefficients
                 # its backward pass reads (no running-statistics update: the split path below owns them)
@@ -961,6 +1001,18 @@ class Engine:
                            self.bufs[t2.buf] if t2 is not None else None,
                            t2.ld if t2 is not None else 0, t2.choff if t2 is not None else 0, border=lay.border,
                            dst_pad=self._pad_for(t.W), dst2_pad=self._pad_for(t2.W) if t2 is not None else 0)
+
+    def _stem_split_forward(self, lay):
+        """The first block of the "mixed" training precision: batch statistics of the split-operand conv output (nothing
+        stored), coefficients, then conv + BatchNorm + LeakyReLU + MaxPool recomputed into the consumer's hi | lo planes."""
+        bn, t = lay.bn, lay.out_t
+        ops.stem_block_stats(self.B, lay.H, lay.W, lay.sh_img, lay.sh_wp, lay.stats, x_lo=lay.sh_img_lo, wp_lo=lay.sh_wp_lo)
+        ops.bn_coeffs(lay.stats, lay.cout, lay.M, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, True,
+                      lay.scale, lay.shift, lay.mean, lay.invstd, momentum=bn.momentum if bn.momentum is not None else 0.1,
+                      eps=bn.eps)
+        ops.stem_block_fwd(self.B, lay.H, lay.W, lay.sh_img, lay.sh_wp, bn.weight.data, bn.bias.data, None, None, False,
+                           lay.scale, lay.shift, lay.mean, lay.invstd, lay.slope, self.bufs[t.buf], t.ld, t.choff, None,
+                           eps=bn.eps, cout=lay.cout, planes=self.act_planes, x_lo=lay.sh_img_lo, wp_lo=lay.sh_wp_lo)
 
     # ------------------------------------------------------------------ backward
     def bn_act_bwd_layer(self, lay, g, g_ld, g_choff, g2, g2_ld, g2_choff, dy, dgamma, dbeta, grad_scale):

@@ -359,18 +359,57 @@ def _stem_desc(B, H, W, x, wp, gamma, beta, scale, shift, mean, invstd, slope):
 
 
 def stem_block_fwd(B, H, W, x, wp, gamma, beta, rmean, rvar, training, scale, shift, mean, invstd, slope, dst, dst_ld,
-                   dst_choff, workspace, momentum=0.1, eps=1e-5, cout=32, planes=1):
+                   dst_choff, workspace, momentum=0.1, eps=1e-5, cout=32, planes=1, x_lo=None, wp_lo=None):
     """The first block in one call: conv1 (3 -> 32, 3x3) + BatchNorm + LeakyReLU + MaxPool(2,2) from the NHWC4 image
     `x` to the pooled padded-NHWC `dst`; the raw conv output is never stored (include/mcamd.h, mcamd_stem_block_desc).
-    training: batch statistics from the image windows' Gram matrix, scale / shift / mean / invstd are written."""
+    training: batch statistics from the image windows' Gram matrix, scale / shift / mean / invstd are written
+    (`dst` None: that half only).  `x_lo` / `wp_lo`: split operands (training must be False: scale / shift are read)."""
     d = _stem_desc(B, H, W, x, wp, gamma, beta, scale, shift, mean, invstd, slope)
     d.running_mean = rmean.data_ptr() if rmean is not None else None
     d.running_var = rvar.data_ptr() if rvar is not None else None
     d.momentum, d.eps, d.training = momentum, eps, 1 if training else 0
     d.cout, d.planes = cout, planes
-    d.dst, d.dst_ld, d.dst_choff = dst.data_ptr(), dst_ld, dst_choff
+    d.dst, d.dst_ld, d.dst_choff = (dst.data_ptr() if dst is not None else None), dst_ld, dst_choff
+    d.x_lo = x_lo.data_ptr() if x_lo is not None else None
+    d.wp_lo = wp_lo.data_ptr() if wp_lo is not None else None
     check(L.lib().mcamd_stem_block_fwd(C.byref(d), ptr(workspace), workspace.numel() if workspace is not None else 0,
                                        stream_ptr()), "mcamd_stem_block_fwd")
+
+
+def stem_block_stats_rows(B, H, W):
+    d = StemBlockDesc()
+    d.B, d.H, d.W = B, H, W
+    return int(L.lib().mcamd_stem_block_stats_rows(C.byref(d)))
+
+
+def stem_block_stats(B, H, W, x, wp, stats, x_lo=None, wp_lo=None):
+    """Per-channel partial sums / sums of squares of the first block's conv output (split operands with `x_lo` /
+    `wp_lo`) into the fp32 slab `stats` [stem_block_stats_rows][2][ld]: what bn_coeffs takes.  Nothing else is written."""
+    _need_cuda(x, wp, stats)
+    assert stats.dtype == torch.float32 and stats.dim() == 3 and stats.shape[1] == 2 and stats.is_contiguous()
+    d = StemBlockDesc()
+    d.B, d.H, d.W = B, H, W
+    d.x, d.wp = x.data_ptr(), wp.data_ptr()
+    d.x_lo = x_lo.data_ptr() if x_lo is not None else None
+    d.wp_lo = wp_lo.data_ptr() if wp_lo is not None else None
+    d.cout = 32
+    check(L.lib().mcamd_stem_block_stats(C.byref(d), ptr(stats), stats.shape[0], stats.shape[2], stream_ptr()),
+          "mcamd_stem_block_stats")
+
+
+def nchw_to_nhwc4_split(src, hi, lo):
+    """fp32 NCHW 3-channel image -> padded NHWC4 fp16 images hi = fp16(v), lo = fp16(v - hi)."""
+    _need_cuda(src, hi, lo)
+    assert src.dtype == torch.float32 and src.is_contiguous() and src.shape[1] == 3
+    B, _, H, W = src.shape
+    check(L.lib().mcamd_nchw_f32_to_nhwc4_split(ptr(src), B, H, W, ptr(hi), ptr(lo), stream_ptr()), "mcamd_nchw_f32_to_nhwc4_split")
+
+
+def pack_stem_split(w, mask, wp_hi, wp_lo):
+    """Stem packing of fp16(w * mask) and of the residual fp16(w * mask - hi) (split operands of the first block)."""
+    _need_cuda(w, wp_hi, wp_lo)
+    assert w.dtype == torch.float32 and w.is_contiguous() and tuple(w.shape[1:]) == (3, 3, 3)
+    check(L.lib().mcamd_pack_stem_split(ptr(w), ptr(mask), w.shape[0], ptr(wp_hi), ptr(wp_lo), stream_ptr()), "mcamd_pack_stem_split")
 
 
 def stem_block_bwd(B, H, W, x, wp, gamma, scale, shift, mean, invstd, slope, g, g_ld, g_choff, dw, dgamma, dbeta, workspace,

@@ -413,6 +413,47 @@ def test_split_forward_two_planes_equals_three(dev, B, H, W, C_, cout, k):
         ops.conv_fwd_raw32(ops.geom(B, H, W, k, 3 * C_, cout, ld2, x_wrap=2 * C_ - 16), x2, wp, outs[0][0], cout, 0, None)
 
 
+@pytest.mark.parametrize("B,H,W,cout", [(2, 56, 56, 64), (3, 37, 39, 64), (2, 48, 50, 40)])
+def test_small3x3_split_kernel(dev, setenv, B, H, W, cout):
+    """conv_small.hip small3x3_split_kernel -- the conv2 shape (32 -> <= 64 channels, 3x3, huge image) on split operands
+    stored as two planes [x_hi | x_lo] with the K-concatenated packing [w_hi | w_hi | w_lo] (x_wrap = 64): weights
+    resident in registers, three MFMAs per loaded fragment pair, fp32 raw output + statistics.  Against float64 torch
+    (2e-6), against the LDS-staged implicit GEMM on the same operands (MCAMD_SMALL3X3=0: another summation order, 1e-6)
+    and the statistics slab against the sums of its own output.  Ragged M and a ragged filter count included."""
+    C_ = 32
+    gen = torch.Generator().manual_seed(B * H + cout)
+    x = torch.randn(B, C_, H, W, generator=gen)
+    w = torch.randn(cout, C_, 3, 3, generator=gen) * (2.0 / (C_ * 9)) ** 0.5
+    hi = x.half().float()
+    lo = (x - hi).half().float()
+    ld2 = 2 * C_
+    x2 = ops.alloc_padded(B, H, W, ld2, dev)
+    ops.nchw_to_padded(hi.to(dev).contiguous(), x2, ld2, 0)
+    ops.nchw_to_padded(lo.to(dev).contiguous(), x2, ld2, C_)
+    g2 = ops.geom(B, H, W, 3, 3 * C_, cout, ld2, x_wrap=2 * C_)
+    wp = torch.zeros(ops.packed_elems(g2)[0], dtype=torch.float16, device=dev)
+    ops.pack_many(*ops.pack_table([dict(w=w.to(dev).contiguous(), mask=None, rows=None, cols=None, cout=cout, cin=C_, ksize=3,
+                                        dst_fwd=wp, dst_dgrad=None, split=True)], dev))
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    outs = []
+    for sw in ("1", "0"):
+        setenv("MCAMD_SMALL3X3", sw)
+        y = torch.full((B * H * W * cout,), float("nan"), device=dev)
+        rows = ops.stats_rows(g2, L.EPI_RAW_F32)
+        stats = torch.full((rows, 2, ops.round_up(cout, 256)), float("nan"), device=dev)
+        stats[:, :, cout:] = 0
+        ops.conv_fwd_raw32(g2, x2, wp, y, cout, 0, stats)
+        got = y.view(B, H, W, cout).permute(0, 3, 1, 2).cpu()
+        assert rel_l2(got, ref) < 2e-6
+        yd = y.view(-1, cout).double()
+        assert torch.allclose(stats[:, 0, :cout].double().sum(0), yd.sum(0), rtol=1e-5, atol=1e-3)
+        assert torch.allclose(stats[:, 1, :cout].double().sum(0), (yd * yd).sum(0), rtol=1e-5)
+        outs.append((got, rows))
+    M = B * H * W
+    assert outs[0][1] == min(256, -(-(-(-M // 32)) // 8))      # mcamd_small3x3_rows: one contiguous run per workgroup
+    assert rel_l2(outs[0][0], outs[1][0]) < 1e-6
+
+
 def test_step_flags_kernel(dev):
     """mcamd_step_flags (train.StepGuard's device-side decision in one launch): [any engine overflow, loss not finite,
     transport overflow], found_inf = EXACTLY 1.0 when any of them fired (torch's fused SGD tests `== 1`: a sum of two
@@ -543,6 +584,84 @@ def test_stem_block_fwd_bwd(dev, B, H, W, masked, training):
         assert float(dgamma[5].abs()) < 1e-6 * float(gl.grad.abs().max())
         assert bool((dw.cpu()[mask == 0] == 0).all())
     assert rel_l2(dgamma.cpu(), gl.grad) < TOL
+
+
+@pytest.mark.parametrize("B,H,W,masked,planes", [(2, 32, 64, False, 2), (3, 64, 96, True, 3), (2, 416, 416, False, 2)])
+def test_stem_block_split_operands(dev, B, H, W, masked, planes):
+    """The first block of the "mixed" TRAINING precision (csrc/conv_stem_block.hip, SPLIT): hi / lo NHWC4 images
+    (mcamd_nchw_f32_to_nhwc4_split) and hi / lo weights (mcamd_pack_stem_split) -> batch statistics from a pass that stores
+    nothing (mcamd_stem_block_stats + mcamd_bn_coeffs) -> conv + BatchNorm + LeakyReLU + MaxPool written as hi | lo planes.
+    Against float64 torch of the four reference ops (nets.py:798-821) on the UNROUNDED fp32 image and weights: the pooled
+    activation hi + lo within 2e-6, the statistics within 1e-6 -- the same unit on plain operands sits at 2e-4."""
+    cout = 32
+    gen = torch.Generator().manual_seed(77 + H)
+    x = torch.rand(B, 3, H, W, generator=gen)
+    w = torch.randn(cout, 3, 3, 3, generator=gen) * 0.3
+    mask = (torch.rand(cout, 3, 3, 3, generator=gen) > 0.4).float() if masked else None
+    if masked:
+        mask[5] = 0.0
+    gamma, beta = torch.rand(cout, generator=gen) + 0.5, torch.randn(cout, generator=gen) * 0.2
+    rm0, rv0 = torch.randn(cout, generator=gen) * 0.1, torch.rand(cout, generator=gen) + 0.5
+    rm_ref, rv_ref = rm0.double().clone(), rv0.double().clone()
+    wl = (w * mask if masked else w).double()
+    y = F.conv2d(x.double(), wl, None, 1, 1)
+    out = F.max_pool2d(F.leaky_relu(F.batch_norm(y, rm_ref, rv_ref, gamma.double(), beta.double(), True, 0.1, 1e-5), 0.1), 2, 2)
+
+    xd = x.to(dev)
+    hi, lo = ops.alloc_padded(B, H, W, 4, dev), ops.alloc_padded(B, H, W, 4, dev)
+    ops.nchw_to_nhwc4_split(xd, hi, lo)
+    vh = ops.padded_view(hi, B, H, W, 4)[:, 1:-1, 1:-1].float().cpu()
+    vl = ops.padded_view(lo, B, H, W, 4)[:, 1:-1, 1:-1].float().cpu()
+    assert torch.equal(vh[..., :3], q16(x).permute(0, 2, 3, 1)) and float(vh[..., 3].abs().max()) == 0.0
+    assert torch.equal(vl[..., :3], q16(x - q16(x)).permute(0, 2, 3, 1)) and float(vl[..., 3].abs().max()) == 0.0
+    assert halo_is_zero(hi, B, H, W, 4) and halo_is_zero(lo, B, H, W, 4)
+    g = ops.geom(B, H, W, 3, 3, cout, 4, 0, stem=1)
+    wp_ref, _ = ops.pack_weights(g, w.to(dev).contiguous(), mask.to(dev) if masked else None)
+    wp, wp_lo = torch.zeros_like(wp_ref), torch.zeros_like(wp_ref)
+    ops.pack_stem_split(w.to(dev).contiguous(), mask.to(dev) if masked else None, wp, wp_lo)
+    assert torch.equal(wp, wp_ref)
+    wlo_ref, _ = ops.pack_weights(g, ((w * mask if masked else w) - q16(w * mask if masked else w)).to(dev).contiguous(), None)
+    assert torch.equal(wp_lo, wlo_ref)
+
+    rows = ops.stem_block_stats_rows(B, H, W)
+    stats = torch.full((rows, 2, 256), float("nan"), device=dev)
+    stats[:, :, 32:] = 0
+    ops.stem_block_stats(B, H, W, hi, wp, stats, x_lo=lo, wp_lo=wp_lo)
+    rm, rv = rm0.to(dev), rv0.to(dev)
+    scale, shift, mean, invstd = (torch.empty(cout, device=dev) for _ in range(4))
+    ops.bn_coeffs(stats, cout, B * H * W, gamma.to(dev), beta.to(dev), rm, rv, True, scale, shift, mean, invstd)
+    assert torch.allclose(mean.cpu().double(), y.mean((0, 2, 3)), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(invstd.cpu().double(), 1.0 / torch.sqrt(y.var((0, 2, 3), unbiased=False) + 1e-5), rtol=2e-6)
+    assert torch.allclose(rm.cpu().double(), rm_ref, rtol=1e-6, atol=1e-6) and torch.allclose(rv.cpu().double(), rv_ref, rtol=1e-5)
+    # the statistics pass on plain operands: sums of the fp16-operand product (the same launch without lo parts)
+    stats1 = torch.zeros(rows, 2, 256, device=dev)
+    ops.stem_block_stats(B, H, W, hi, wp, stats1)
+    y16 = F.conv2d(q16(x).double(), q16(wl.float()).double(), None, 1, 1)
+    assert torch.allclose(stats1[:, 0, :32].double().sum(0).cpu(), y16.sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+
+    ld = 32 * planes + 32
+    dst = ops.alloc_padded(B, H // 2, W // 2, ld, dev)
+    ops.stem_block_fwd(B, H, W, hi, wp, gamma.to(dev), beta.to(dev), None, None, False, scale, shift, mean, invstd, 0.1,
+                       dst, ld, 32, None, planes=planes, x_lo=lo, wp_lo=wp_lo)
+    got_hi = padded_to_nchw(dst, B, H // 2, W // 2, ld, cout, 32).double()
+    got_lo = padded_to_nchw(dst, B, H // 2, W // 2, ld, cout, 64).double()
+    e = rel_l2(got_hi + got_lo, out)
+    print("split stem block %dx%dx%d: hi + lo %.1e, hi alone %.1e" % (B, H, W, e, rel_l2(got_hi, out)))
+    assert e < 2e-6
+    assert rel_l2(got_hi, out) < 4e-4                      # the hi plane alone = the fp16 rounding of the activation
+    if planes == 3:
+        assert torch.equal(padded_to_nchw(dst, B, H // 2, W // 2, ld, cout, 96).double(), got_hi)
+    assert halo_is_zero(dst, B, H // 2, W // 2, ld)
+    assert float(ops.padded_view(dst, B, H // 2, W // 2, ld)[..., :32].abs().max()) == 0.0      # the slice's neighbour
+    # statistics-only call of the plain block (dst None): coefficients and context, no output
+    ws = torch.empty(ops.stem_block_workspace_bytes(), dtype=torch.uint8, device=dev)
+    c = [torch.empty(cout, device=dev) for _ in range(4)]
+    ops.stem_block_fwd(B, H, W, hi, wp, gamma.to(dev), beta.to(dev), None, None, True, c[0], c[1], c[2], c[3], 0.1,
+                       None, 0, 0, ws, momentum=0.0)
+    assert torch.allclose(c[2].cpu().double(), y16.mean((0, 2, 3)), rtol=1e-4, atol=1e-5)
+    with pytest.raises(L.McamdError):       # split operands with training != 0: refused (statistics come from the stats pass)
+        ops.stem_block_fwd(B, H, W, hi, wp, gamma.to(dev), beta.to(dev), None, None, True, scale, shift, mean, invstd, 0.1,
+                           dst, ld, 32, ws, planes=planes, x_lo=lo, wp_lo=wp_lo)
 
 
 @pytest.mark.parametrize("cout", [8, 24])

@@ -70,7 +70,7 @@ for prec in ("fp16", "mixed", "fp16x3"):
         torch.cuda.synchronize()
         ev, eng2.events = eng2.events, None
         per = {}
-        for tag, lay, e0, e1 in ev:
+        for tag, lay, e0, e1, _host in ev:
             per.setdefault((lay.li + 1, tag), []).append(e0.elapsed_time(e1))
         tot = {}
         for (li, tag), v in sorted(per.items()):
