@@ -12,7 +12,8 @@
 // with the reference's quirks kept (region_loss.py header): boxes for the IoU tests use exp(w) * anchor (double exp),
 // tw = gw / anchor, conf_mask enters as its square root on both sides (= conf_mask itself on the squared error),
 // ground-truth rows end at the first x == 0, the later of two boxes in one cell / anchor wins.
-// One workgroup per image: ground-truth rows in LDS, every thread walks predictions n = (anchor, row, column).
+// One workgroup per (image, anchor): ground-truth rows of the image in LDS, every thread walks the predictions (row, column)
+// of its anchor.
 // Deterministic: per-image partial losses, summed in order by a second one-block launch.
 #include "common.h"
 
@@ -116,6 +117,9 @@ __global__ __launch_bounds__(NTHR) void region_loss_kernel(RegionArgs a) {
             th = gh[wt] / a.ah[gbest[wt]];
             tconf = iou_cwh(gx[wt], gy[wt], gw[wt], gh[wt], px, py, pw, ph);
             tcls = (int)gcls[wt];
+            // a label outside [0, C) has no logit: no class term for this box (F.cross_entropy would raise on the torch
+            // path; the kernel cannot, so it contributes nothing instead of reading past the prediction -- ADVICE r03)
+            if (tcls < 0 || tcls >= a.C) tcls = -1;
         }
         const float dx = x - tx, dy = y - ty, dw = w - tw, dh = h - th, dc = conf - tconf;
         float l = a.coord_scale * cm * 0.5f * (dx * dx + dy * dy + dw * dw + dh * dh) + conf_mask * 0.5f * dc * dc;
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(NTHR) void region_loss_kernel(RegionArgs a) {
         a.grad[base + 2 * HW] = a.coord_scale * cm * dw * w * inv_nb;
         a.grad[base + 3 * HW] = a.coord_scale * cm * dh * h * inv_nb;
         a.grad[base + 4 * HW] = conf_mask * dc * conf * (1.f - conf) * inv_nb;
-        if (cm != 0.f) {
+        if (cm != 0.f && tcls >= 0) {
             float mx = -3.4e38f;
             for (int c = 0; c < a.C; ++c) mx = fmaxf(mx, a.out[base + (5 + c) * HW]);
             float se = 0.f;

@@ -841,12 +841,17 @@ class Engine:
 
     # ------------------------------------------------------------------ launch plans
     def _ptr_sig(self):
-        """Addresses of every tensor torch owns that a recorded plan holds (parameters, masks, BatchNorm buffers)."""
+        """Everything a recorded plan holds BY VALUE that torch may change under it: addresses of parameters, masks and
+        BatchNorm buffers, of the engine's own persistent flat-gradient / logit-gradient buffers (MCAMD_DBG_FRESH_FLAT
+        re-allocates them), and the BatchNorm momentum / eps the coefficient kernels were recorded with."""
         sig = [p.data_ptr() for p in self.params]
+        sig.append(self._flat.data_ptr() if self._flat is not None else 0)
+        sig.append(self._gout.data_ptr() if self._gout is not None else 0)
         for lay in self.layers:
             if lay.bn is not None:
                 sig.append(lay.bn.running_mean.data_ptr())
                 sig.append(lay.bn.running_var.data_ptr())
+                sig.append((lay.bn.momentum, lay.bn.eps))
             if lay.conv.mask_flag:
                 sig.append(lay.conv.mask.data_ptr())
         return tuple(sig)

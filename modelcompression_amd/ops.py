@@ -4,6 +4,7 @@ Tensors are only containers for device memory here (allocation + stream come
 from PyTorch-ROCm); every compute call goes to libmcamd.so.
 """
 import ctypes as C
+import weakref
 
 import torch
 
@@ -32,7 +33,7 @@ def guard_elems(W, ld):
     return (round_up(W + 3, 4) + 128) * ld + SLACK
 
 
-_PAD_OF = {}     # data_ptr of a buffer from alloc_padded -> its form (0 padded, 1 shared-halo): padded_view finds it there
+_PAD_OF = {}     # data_ptr -> weak reference to the shared-halo buffer alloc_padded returned at that address
 
 
 def alloc_padded(B, H, W, ld, device, pad=0):
@@ -43,15 +44,27 @@ def alloc_padded(B, H, W, ld, device, pad=0):
     g = guard_elems(W, ld)
     full = torch.zeros(g + n + g, dtype=HALF, device=device)
     buf = full[g:g + n + SLACK]
+    # the form travels ON the tensor object; the address registry serves other tensor objects over the same memory and is
+    # validated by a weak reference, so an address reused after the buffer died never reports a stale form
+    buf._mcamd_pad = 1 if pad else 0
     if pad:
-        _PAD_OF[buf.data_ptr()] = 1
+        _PAD_OF[buf.data_ptr()] = weakref.ref(buf)
     else:
         _PAD_OF.pop(buf.data_ptr(), None)
     return buf
 
 
 def pad_of(buf):
-    return _PAD_OF.get(buf.data_ptr(), 0)
+    form = getattr(buf, "_mcamd_pad", None)
+    if form is not None:
+        return form
+    ref = _PAD_OF.get(buf.data_ptr())
+    if ref is None:
+        return 0
+    if ref() is None:                      # the buffer that registered this address is gone
+        del _PAD_OF[buf.data_ptr()]
+        return 0
+    return 1
 
 
 def padded_view(buf, B, H, W, ld, pad=None):

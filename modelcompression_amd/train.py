@@ -73,6 +73,15 @@ class StepGuard:
             self._host = self._host.pin_memory()
         self._event, self._pending = None, False
         self.skipped = 0
+        # scales the pending step RAN with: its flag is read one step late, when the next step -- enqueued with the same
+        # scales -- has usually overflowed too; a flag only halves a scale that is still the one its step used, so one
+        # overflow event costs one halving, not two.  `clean` counts steps since the last skip: after
+        # GROWTH_INTERVAL of them a halved scale doubles again (up to where it started), as torch.amp.GradScaler does --
+        # otherwise a long run only ever loses gradient bits.
+        self._pending_scales = (None, None)
+        self._scale0 = float(getattr(model, "grad_scale", 1.0))
+        self._tscale0 = None
+        self.clean = 0
         self._collective = dist.is_initialized() and (dist.get_world_size() > 1 or dp.rehearsal())
 
     def consume(self):
@@ -85,24 +94,43 @@ class StepGuard:
         self._pending = False
         if bad:
             raise FloatingPointError("non-finite training loss")
+        ran_gs, ran_ts = self._pending_scales
+        red = getattr(self.model, "_grad_reducer", None)
         if over or tover:
             self.skipped += 1
-        if over:
+            self.clean = 0
+        else:
+            self.clean += 1
+        if over and (ran_gs is None or ran_gs == self.model.grad_scale):
             self.model.grad_scale = max(1.0, self.model.grad_scale / 2.0)
             if self.log:
                 self.log('gradient overflow in fp16 storage: step skipped, grad_scale -> %g' % self.model.grad_scale)
-        if tover:
-            red = self.model._grad_reducer
+        if tover and (ran_ts is None or ran_ts == red.fp16_scale):
             red.fp16_scale = max(1.0 / 65536.0, red.fp16_scale / 2.0)
             if self.log:
                 self.log('gradient overflow in the fp16 all-reduce transport: step skipped, fp16_scale -> %g' % red.fp16_scale)
+        if self.clean >= self.GROWTH_INTERVAL:
+            self.clean = 0
+            if self.model.grad_scale < self._scale0:
+                self.model.grad_scale = min(self._scale0, self.model.grad_scale * 2.0)
+                if self.log:
+                    self.log('%d clean steps: grad_scale -> %g' % (self.GROWTH_INTERVAL, self.model.grad_scale))
+            if red is not None and self._tscale0 is not None and red.fp16_scale < self._tscale0:
+                red.fp16_scale = min(self._tscale0, red.fp16_scale * 2.0)
         return int(over) + 2 * int(bad) + 4 * int(tover)
+
+    GROWTH_INTERVAL = 2000
 
     def decide(self, loss):
         """Call between backward() and optimizer.step()."""
-        self.consume()
-        flags = [eng.overflow for eng in getattr(self.model, "_engines", {}).values()]
         red = getattr(self.model, "_grad_reducer", None)
+        # the scales the step that just ran its backward USED (consume() below may change them for the next one)
+        ran = (float(getattr(self.model, "grad_scale", 1.0)), red.fp16_scale if red is not None else None)
+        if red is not None and self._tscale0 is None:
+            self._tscale0 = red.fp16_scale
+        self.consume()
+        self._pending_scales = ran
+        flags = [eng.overflow for eng in getattr(self.model, "_engines", {}).values()]
         tflag = red.overflow if red is not None else None
         if (self.dev.type == "cuda" and len(flags) <= 8 and loss.dtype == torch.float32 and loss.numel() == 1
                 and all(f.is_cuda and f.dtype == torch.int32 for f in flags + ([tflag] if tflag is not None else []))):

@@ -315,6 +315,22 @@ def _dp_worker(rank, world, port, tmp):
         raise AssertionError("non-finite loss accepted")
     except FloatingPointError:
         pass
+    # the late read: step N overflows, step N + 1 is enqueued with the SAME scale and overflows too -- both
+    # are skipped on the device, but the scale is halved once, not twice; and after GROWTH_INTERVAL clean steps it grows back
+    gs0, sk0 = net.grad_scale, guard.skipped
+    one_step(engine_over=True)
+    one_step(engine_over=True)
+    one_step()
+    one_step()
+    b1 = 0.9 * mom + 1.0                                     # momentum buffer after the two clean steps that did update
+    assert net.grad_scale == gs0 / 2 and guard.skipped == sk0 + 2
+    assert torch.allclose(net.w.detach(), w_before - 0.5 * b1 - 0.5 * (0.9 * b1 + 1.0))
+    guard.GROWTH_INTERVAL = 3
+    guard.clean = 0
+    for _ in range(4):
+        one_step()
+    assert net.grad_scale == gs0
+    guard.finish()
     try:
         one_step(loss=float("nan") if rank == 0 else 1.0)   # a non-finite loss on ONE rank raises on both, one step late
         guard.finish()
