@@ -296,6 +296,16 @@ typedef struct mcamd_act_bwd_desc {
     int32_t skip_dead_param_grads; /* n > 0: dgamma / dbeta of the physical channels c >= n are NOT written -- the
                                   consumer that folded those dead channels delivers their gradients
                                   (mcamd_unfold_wgrad) and `g` holds nothing for them; 0 = write all */
+    const void* act;           /* optional, PLAIN blocks without g2: the activation the forward pass stored for the consumer
+                                  (fp16, padded NHWC / shared-halo form per act_pad, the hi plane of split storage) at channels
+                                  [act_choff, act_choff + C) of rows of act_ld.  LeakyReLU is invertible: z = act > 0 ? act :
+                                  act / slope, xhat = (z - beta) / gamma -- so `y` (fp32, y_dtype 1, or NULL) is read only by
+                                  the threads that hold a channel with gamma == 0, where xhat cannot be recovered (NULL: the
+                                  dgamma of such a channel is written as 0).  With an fp32 `y` (split-operand precisions) the
+                                  two passes read half the bytes; the result carries the fp16 rounding of the stored
+                                  activation, as every backward tensor does (nn.BatchNorm2d + nn.LeakyReLU backward,
+                                  reference src/nets.py:802-809 under autograd). */
+    int32_t act_ld, act_choff, act_pad;
 } mcamd_act_bwd_desc;
 size_t mcamd_bn_act_bwd_workspace_bytes(const mcamd_act_bwd_desc* d);
 int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, size_t workspace_bytes, void* stream);

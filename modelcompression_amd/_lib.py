@@ -60,7 +60,8 @@ class ActBwdDesc(C.Structure):
                 ("dy", C.c_void_p), ("dy_ld", C.c_int32), ("dy_choff", C.c_int32),
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("grad_scale", C.c_float),
                 ("dy_keep", C.c_void_p), ("chan_perm", C.c_void_p), ("y_dtype", C.c_int32),
-                ("overflow", C.c_void_p), ("dy_pad", C.c_int32), ("skip_dead_param_grads", C.c_int32)]
+                ("overflow", C.c_void_p), ("dy_pad", C.c_int32), ("skip_dead_param_grads", C.c_int32),
+                ("act", C.c_void_p), ("act_ld", C.c_int32), ("act_choff", C.c_int32), ("act_pad", C.c_int32)]
 
 
 class FoldDesc(C.Structure):

@@ -254,6 +254,8 @@ struct ActBwdArgs {
     float slope;
     long long items;
     int dy_pw;             // 2: dy in the padded form, 1: shared-halo form
+    const half_t* act;     // optional (bn_plain_bwd_act_kernel): the block's stored activation, padded NHWC fp16
+    int act_ld, act_choff, act_pw;
 };
 
 // PHASE 0: per-channel sums of g_z and g_z*xhat -> slab.  PHASE 1: dy -> padded NHWC.
@@ -482,6 +484,98 @@ __global__ __launch_bounds__(256) void bn_plain_bwd_kernel(ActBwdArgs a) {
             if (h >= a.H) h -= a.H, ++b;
             b += sb_;
         }
+    }
+    if (PHASE == 1 && satmax > 65504.f && a.overflow) atomicOr(a.overflow, 1);
+    if (PHASE == 0) {
+        block_partials_to_slab(sb, sg, CH, a.slab, a.C);
+    }
+}
+
+// The same two passes WITHOUT the saved raw output: LeakyReLU is invertible, so a PLAIN block's pre-activation is
+// recovered from the activation the forward pass stored for the consumer (fp16, the hi plane of split storage):
+// z = a > 0 ? a : a / slope, xhat = (z - beta) / gamma.  With the split-operand precisions the saved y is fp32: the two
+// passes read 2 instead of 4 bytes per element for it (0.89 -> 0.65 ms per "mixed" B=64 step), at the operand precision
+// every backward pass has anyway (G and dY are fp16).  With dm = gamma invstd (0 for a pruned filter):
+//     out = dm g_z - (P z + Q),   P = dm c2 / gamma,  Q = dm c1 - P beta     (per channel, hoisted)
+// A channel with gamma == 0 has no xhat to recover (its dY is 0 either way, dm = 0): the threads that hold such a channel
+// read the saved fp32 y for their dgamma sums in pass 0, as the y kernel does -- a branch nobody takes on a trained network.
+template <int PHASE>
+__global__ __launch_bounds__(256) void bn_plain_bwd_act_kernel(ActBwdArgs a) {
+    const int CH = a.C >> 3, lg = __ffs(CH) - 1;        // C / 8 is a power of two (check_c)
+    const int c8 = (threadIdx.x & (CH - 1)) * 8;
+    float sc[8], sh[8], mu[8], is[8], beta[8], rg[8], P[8], Q[8], dm[8];
+    loadf8(a.scale + c8, sc);
+    loadf8(a.shift + c8, sh);
+    loadf8(a.mean + c8, mu);
+    loadf8(a.invstd + c8, is);
+    bool need_y = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        beta[i] = sh[i] + mu[i] * sc[i];                 // shift = beta - mean scale
+        rg[i] = sc[i] != 0.f ? is[i] / sc[i] : 0.f;      // 1 / gamma (scale = gamma invstd)
+        need_y |= sc[i] == 0.f;
+    }
+    need_y = need_y && PHASE == 0 && a.y != nullptr;
+    if (PHASE == 1) {
+        float c1[8], c2[8];
+        loadf8(a.coef + c8, c1);
+        loadf8(a.coef + a.C + c8, c2);
+        if (a.dy_keep) {
+            float kp[8];
+            loadf8(a.dy_keep + c8, kp);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dm[i] = kp[i] != 0.f ? sc[i] : 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dm[i] = sc[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            P[i] = dm[i] * c2[i] * rg[i];
+            Q[i] = dm[i] * c1[i] - P[i] * beta[i];
+        }
+    }
+    float sb[8], sg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sb[i] = sg[i] = 0.f;
+    float satmax = 0.f;
+    const float inv_slope = 1.0f / a.slope;
+    const int HW = a.H * a.W;
+    const unsigned npix = (unsigned)(a.items >> lg);
+    const unsigned stride = (gridDim.x * 256u) >> lg;                      // pixels per grid stride
+    unsigned pix = (blockIdx.x * 256u + threadIdx.x) >> lg;
+    int b = (int)(pix / (unsigned)HW), rem = (int)(pix - (unsigned)b * (unsigned)HW);
+    int h = rem / a.W, w = rem - h * a.W;
+    const int sb_ = (int)(stride / (unsigned)HW), srem = (int)(stride - (unsigned)sb_ * (unsigned)HW);
+    const int sh_ = srem / a.W, sw_ = srem - sh_ * a.W;
+    for (; pix < npix; pix += stride) {
+        float av[8], gv[8];
+        load8(a.act + pad_off(b, h, w, a.H, a.W, a.act_ld, a.act_pw) + a.act_choff + c8, av);
+        load8(a.g + (long long)pix * a.g_ld + a.g_choff + c8, gv);
+        float out[8], yv[8];
+        if (need_y) load_y<true>(a.y, (long long)pix * a.y_ld + a.y_choff + c8, yv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool pos = av[i] > 0.f;
+            const float z = pos ? av[i] : av[i] * inv_slope;
+            const float gz = pos ? gv[i] : gv[i] * a.slope;
+            if (PHASE == 0) {
+                sb[i] += gz;
+                float xh = (z - beta[i]) * rg[i];
+                if (need_y && sc[i] == 0.f) xh = (yv[i] - mu[i]) * is[i];
+                sg[i] += gz * xh;
+            } else {
+                const float o = dm[i] * gz - (P[i] * z + Q[i]);
+                out[i] = o;
+                satmax = fmaxf(satmax, fabsf(o));
+            }
+        }
+        if (PHASE == 1) store8(a.dy + pad_off(b, h, w, a.H, a.W, a.dy_ld, a.dy_pw) + a.dy_choff + c8, out);
+        w += sw_;
+        if (w >= a.W) w -= a.W, ++h;
+        h += sh_;
+        if (h >= a.H) h -= a.H, ++b;
+        b += sb_;
     }
     if (PHASE == 1 && satmax > 65504.f && a.overflow) atomicOr(a.overflow, 1);
     if (PHASE == 0) {
@@ -843,7 +937,7 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
         const mcamd_act_bwd_desc d_ = *d;
         return mcamd_rec_push(stream, [=](void* s) { return mcamd_bn_act_bwd(&d_, workspace, workspace_bytes, s); });
     }
-    MCAMD_REQUIRE(d && d->y && d->g && d->dy && d->scale && d->shift && d->mean && d->invstd && workspace,
+    MCAMD_REQUIRE(d && (d->y || d->act) && d->g && d->dy && d->scale && d->shift && d->mean && d->invstd && workspace,
                   "bn_act_bwd: null argument");
     if (check_c(d->C, "bn_act_bwd")) return MCAMD_EINVAL;
     if (workspace_bytes < mcamd_bn_act_bwd_workspace_bytes(d)) {
@@ -874,6 +968,19 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
     MCAMD_REQUIRE(d->dy_pad == 0 || d->dy_pad == 1, "bn_act_bwd: dy_pad must be 0 or 1");
     a.dy_pw = d->dy_pad ? 1 : 2;
     a.slope = d->slope;
+    a.act = (const half_t*)d->act;
+    a.act_ld = d->act_ld, a.act_choff = d->act_choff;
+    a.act_pw = d->act_pad ? 1 : 2;
+    if (d->act) {
+        MCAMD_REQUIRE(d->mode == MCAMD_DST_PLAIN && !d->g2, "bn_act_bwd: `act` (backward from the stored activation) is for PLAIN "
+                                                          "blocks without a second gradient");
+        MCAMD_REQUIRE(d->act_ld % 8 == 0 && d->act_choff % 8 == 0 && d->act_choff + d->C <= d->act_ld &&
+                          (d->act_pad == 0 || d->act_pad == 1),
+                      "bn_act_bwd: activation slice [%d, %d) does not fit act_ld %d", d->act_choff, d->act_choff + d->C, d->act_ld);
+        MCAMD_REQUIRE(d->slope > 0.f, "bn_act_bwd: `act` needs an invertible activation (slope > 0)");
+        MCAMD_REQUIRE(!d->y || d->y_dtype == 1, "bn_act_bwd: with `act`, `y` is NULL or the fp32 raw output (read for channels "
+                                                "whose gamma is 0 only)");
+    }
     long long pixels = (long long)d->B * d->H * d->W;
     double count = (double)pixels;
     if (d->mode != MCAMD_DST_PLAIN) pixels /= 4;
@@ -911,9 +1018,11 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
     const bool plain_fast = MCAMD_ENV_INT("MCAMD_BN_PLAIN_FAST", 1) != 0 &&
                             d->mode == MCAMD_DST_PLAIN && !d->g2 && a.items < (1ll << 31) &&
                             (unsigned long long)grid * 256ull < (1ull << 31);
+    MCAMD_REQUIRE(!d->act || plain_fast, "bn_act_bwd: `act` needs the plain fast path (fewer than 2^31 items)");
 #define PLAIN_LAUNCH(PHASE)                                                                                       \
     do {                                                                                                          \
-        if (y32) hipLaunchKernelGGL((bn_plain_bwd_kernel<PHASE, true>), dim3(grid), dim3(256), 0, st, a);         \
+        if (a.act) hipLaunchKernelGGL((bn_plain_bwd_act_kernel<PHASE>), dim3(grid), dim3(256), 0, st, a);         \
+        else if (y32) hipLaunchKernelGGL((bn_plain_bwd_kernel<PHASE, true>), dim3(grid), dim3(256), 0, st, a);    \
         else hipLaunchKernelGGL((bn_plain_bwd_kernel<PHASE, false>), dim3(grid), dim3(256), 0, st, a);            \
     } while (0)
     if (pool_fast) POOL_LAUNCH(0);

@@ -267,13 +267,14 @@ class Darknet(nn.Module):
         self._last_flat_grad = None
         self._anchor = None             # the one differentiable input of the autograd node (see _DarknetFn)
         self.grad_scale = 256.0         # fp16 gradient scaling inside the engine, undone in fp32
-        # Operand precision of the forward convolutions (engine.py): "fp16" (throughput), "fp16x3" (split hi/lo
-        # operands, three fp16 MFMA products per multiply), "mixed" (split except on the costliest blocks the 1e-3
-        # logit budget leaves plain -- in eval AND in training, where the budget is tighter: engine.MIXED_BUDGET_TRAIN),
-        # or "auto" = "fp16" while training, "mixed" in eval mode -- so that inference reproduces the reference's fp32
-        # region-layer logits within 1e-3 (north_star) by default.  Training in plain fp16 does NOT meet 1e-3 end to
-        # end on a random-init network (3.3e-2 at B=64; the fp32 oracle with fp16-rounded storage: 3.7e-2); training in
-        # "mixed" does, at ~0.6 of the throughput (bench.py reports both).
+        # Operand precision of the forward convolutions (engine.py): "fp16" (plain operands: the throughput opt-in),
+        # "fp16x3" (split hi/lo operands on every block, three fp16 MFMA products per multiply), "mixed" (split except on
+        # the costliest blocks the 1e-3 logit budget leaves plain -- in eval AND in training, where the budget is tighter:
+        # engine.MIXED_BUDGET_TRAIN), or "auto" = "mixed" in BOTH modes (round 4) -- so that the drop-in reproduces the
+        # reference's fp32 region-layer logits within 1e-3 (north_star) by default, as the reference itself computes in
+        # fp32 end to end (layers.py:59-64, train.py:224-235).  Training in plain fp16 does NOT meet 1e-3 end to end on
+        # a random-init network (3.2e-2 at B=64; the fp32 oracle with fp16-rounded storage: 3.7e-2) and is 1.35x faster:
+        # `model.precision = "fp16"` / MCAMD_PRECISION=fp16 selects it explicitly (bench.py reports both).
         self.precision = os.environ.get("MCAMD_PRECISION", "auto")
 
     # ---- engine plumbing
@@ -306,7 +307,7 @@ class Darknet(nn.Module):
         from .engine import Engine
         prec = self.precision
         if prec == "auto":
-            prec = "fp16" if self.training else "mixed"
+            prec = "mixed"
         # "mixed" has two budgets: the training-mode forward amplifies operand rounding of the early blocks (engine.py)
         for_training = bool(self.training and prec == "mixed")
         # training and inference engines differ in their activation layout (the small images of a training engine are in the

@@ -322,12 +322,16 @@ def bn_act_fwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, slope, mode, dst, ds
 
 def bn_act_bwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, mean, invstd, slope, mode, g, g_ld, g_choff, dy, dy_ld,
                dy_choff, dgamma, dbeta, grad_scale=1.0, g2=None, g2_ld=0, g2_choff=0, workspace=None, dy_keep=None,
-               perm=None, overflow=None, skip_dead_from=0, dy_pad=0):
+               perm=None, overflow=None, skip_dead_from=0, dy_pad=0, act=None, act_ld=0, act_choff=0, act_pad=0):
+    """`act` (PLAIN blocks): the stored fp16 activation in its padded buffer -- the pre-activation is recovered from it
+    and `y` is not read (mcamd_act_bwd_desc.act)."""
     d = ActBwdDesc()
     d.skip_dead_param_grads = int(skip_dead_from)
     d.dy_pad = dy_pad
     d.B, d.H, d.W, d.C = B, H, W, C_
-    d.y, d.y_ld, d.y_choff = y.data_ptr(), y_ld, y_choff
+    if act is not None:
+        d.act, d.act_ld, d.act_choff, d.act_pad = act.data_ptr(), act_ld, act_choff, act_pad
+    d.y, d.y_ld, d.y_choff = (y.data_ptr() if y is not None else None), y_ld, y_choff
     d.scale, d.shift, d.mean, d.invstd = scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr()
     d.slope, d.mode = slope, mode
     d.g, d.g_ld, d.g_choff = g.data_ptr(), g_ld, g_choff
@@ -339,11 +343,11 @@ def bn_act_bwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, mean, invstd, slope,
     d.grad_scale = grad_scale
     d.dy_keep = dy_keep.data_ptr() if dy_keep is not None else None
     d.chan_perm = _perm_ptr(perm, C_)
-    d.y_dtype = 1 if y.dtype == torch.float32 else 0
+    d.y_dtype = 1 if (y is not None and y.dtype == torch.float32) else 0
     d.overflow = overflow.data_ptr() if overflow is not None else None
     need = int(L.lib().mcamd_bn_act_bwd_workspace_bytes(C.byref(d)))
     if workspace is None:
-        workspace = torch.empty(need, dtype=torch.uint8, device=y.device)
+        workspace = torch.empty(need, dtype=torch.uint8, device=g.device)
     check(L.lib().mcamd_bn_act_bwd(C.byref(d), ptr(workspace), workspace.numel(), stream_ptr()), "mcamd_bn_act_bwd")
 
 

@@ -369,6 +369,125 @@ def test_data_parallel_reducer_gloo_world2(tmp_path):
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
 
 
+def _dp_worker8(rank, world, port, tmp):
+    """WORLD SIZE 8 (the driver's scaling run) on gloo: bucket order and chunking with eight ranks, the
+    fp16 transport's clamp at +-65504 / 8 with an entry above it, the packed static-mask transport, and train.StepGuard
+    making all eight ranks skip the same step when ONE of them overflowed."""
+    import torch.distributed as dist
+    from modelcompression_amd import dp
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    assert dp.init_from_env("gloo") == (rank, world) and world == 8
+    n = 5000
+    base = torch.arange(n, dtype=torch.float32) / 7.0
+    mean_factor = sum(r + 1 for r in range(world)) / world                     # ranks hold base * (rank + 1)
+    # ---- dense fp32, overlapped buckets reported from the tail, two steps (state resets), chunked collectives
+    red = dp.GradReducer(chunk_elems=900, bucket_elems=1200)
+    for step in range(2):
+        flat = base * (rank + 1) + step
+        n0 = red.collectives
+        edges = [5000, 4600, 3900, 3700, 2000, 1999, 600, 0]
+        for hi, lo in zip(edges[:-1], edges[1:]):
+            red.ready(flat, lo, hi)
+        # buckets: [3700, 5000) (1300 -> 2 chunks), [2000, 3700) (1700 -> 2), [600, 2000) (1400 -> 2), then [0, 600) at finish
+        assert red.collectives - n0 == 6
+        red.finish(flat)
+        assert red.collectives - n0 == 7
+        assert torch.allclose(flat, base * mean_factor + step, rtol=1e-6)
+    ref = flat.clone()
+    gathered = [torch.empty_like(ref) for _ in range(world)]
+    dist.all_gather(gathered, ref)
+    assert all(torch.equal(g, ref) for g in gathered)                          # every rank holds the same bits
+    # ---- packed static-mask transport: kept entries bit-for-bit the dense result, masked entries exact zeros
+    gm = torch.Generator().manual_seed(9)
+    shapes = [(8, 4, 3, 3), (8,), (8,), (6, 8, 1, 1), (6,)]
+    params = [torch.zeros(sh) for sh in shapes]
+    wmasks = [(torch.rand(sh, generator=gm) > 0.8).float() for sh in shapes if len(sh) != 1]
+    full = torch.cat([(wmasks[0] if i == 0 else wmasks[1]).reshape(-1) if len(sh) != 1 else torch.ones(sh[0])
+                      for i, sh in enumerate(shapes)])
+    total = int(full.numel())
+    local = torch.randn(total, generator=torch.Generator().manual_seed(200 + rank)) * full
+    dense = local.clone()
+    dp.GradReducer(transport="fp32").reduce_flat(dense)
+    bounds = [0]
+    for p_ in params:
+        bounds.append(bounds[-1] + p_.numel())
+    sp = dp.GradReducer(bucket_elems=30, transport="fp32")
+    sp.set_static_masks(params, wmasks)
+    flat = local.clone()
+    for lo, hi in ((bounds[3], bounds[5]), (bounds[0], bounds[3])):
+        sp.ready(flat, lo, hi)
+    sp.finish(flat)
+    # (with more than two ranks a ring all-reduce adds the ranks' values in an order that depends on where an element sits
+    # in the collective's buffer, so packed and dense agree to the last bits, not bit for bit as at world size 2)
+    assert torch.allclose(flat, dense, rtol=1e-5, atol=1e-6) and bool((flat[full == 0] == 0).all())
+    assert sp.bytes_reduced == 4 * int(full.sum())
+    allf = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(allf, flat)
+    assert all(torch.equal(t, allf[0]) for t in allf)                          # ... and every rank holds the same bits
+    # ---- fp16 transport at world 8: the clamp is 65504 / 8 = 8188 on the SCALED entry, so that the fp16 sum of eight
+    # clamped entries stays finite; rank 3 alone holds an entry above it
+    h = dp.GradReducer(transport="fp16", fp16_scale=256.0)
+    flat = torch.tensor([40.0, 1.0, -2.0]) if rank == 3 else torch.tensor([1.0, 1.0, -2.0])   # 40 * 256 = 10240 > 8188
+    h.reduce_flat(flat)
+    assert bool(torch.isfinite(flat).all()) and h.transport_overflowed() == (rank == 3)
+    flat = torch.tensor([31.0, 1.0, -2.0])                                     # 31 * 256 = 7936 < 8188 on every rank: 8 x 7936 < 65504
+    h.reduce_flat(flat)
+    assert not h.transport_overflowed() and torch.allclose(flat, torch.tensor([31.0, 1.0, -2.0]), rtol=2e-3)
+    # ---- StepGuard: rank 5 alone saturates its engine gradients -> ALL ranks skip that step; rank 3's transport overflow
+    # one step later -> all ranks skip again; weights stay identical across the ranks throughout
+    from modelcompression_amd.train import StepGuard
+
+    class Eng:
+        def __init__(self):
+            self.overflow = torch.zeros(1, dtype=torch.int32)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(4))
+            self._engines, self.grad_scale = {"e": Eng()}, 256.0
+    net = Net()
+    net._grad_reducer = h
+    opt = torch.optim.SGD(net.parameters(), lr=0.5, momentum=0.0, fused=True)
+    guard = StepGuard(net, opt, torch.device("cpu"))
+
+    def one_step(engine_over=False, grad=1.0):
+        net.w.grad = torch.full((4,), grad)
+        h.reduce_flat(net.w.grad)
+        if engine_over:
+            net._engines["e"].overflow.fill_(1)
+        guard.decide(torch.tensor(1.0))
+        opt.step()
+    one_step()
+    assert torch.allclose(net.w.detach(), torch.full((4,), 0.5), rtol=2e-3)
+    w1 = net.w.detach().clone()
+    one_step(engine_over=(rank == 5))
+    assert torch.equal(net.w.detach(), w1)                                      # skipped on every rank
+    one_step(grad=40.0 if rank == 3 else 1.0)
+    assert torch.equal(net.w.detach(), w1) and guard.skipped == 1 and net.grad_scale == 128.0
+    one_step()
+    assert guard.skipped == 2 and h.fp16_scale == 128.0 and not torch.equal(net.w.detach(), w1)
+    ws = [torch.empty(4) for _ in range(world)]
+    dist.all_gather(ws, net.w.detach().clone())
+    assert all(torch.equal(t, ws[0]) for t in ws)
+    assert guard.finish() == 0
+    assert dp.all_ranks_ok(rank != 6) is False and dp.all_ranks_ok(True) is True
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmp, "ok%d" % rank), "w").write("1")
+
+
+def test_data_parallel_reducer_gloo_world8(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_dp_worker8, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(8))
+
+
 def _dp_rehearsal_worker(tmp):
     """MCAMD_DP_REHEARSE=1 with ONE rank (gloo): the process group exists, the reducer's bucketed asynchronous collectives
     run, and -- being a sum over one rank, with the averaging riding on the engine's 1 / grad_scale -- leave the gradient

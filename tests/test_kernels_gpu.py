@@ -847,6 +847,64 @@ def test_bn_pool_bwd_fast_equals_generic(dev, setenv, C, y_ld, keep_n, mode, dua
     assert bool((ops.padded_view(dy1.to(dev), B, H, W, C)[:, 1:-1, 1:-1, keep_n:] == 0).all())
 
 
+@pytest.mark.parametrize("C,B,H,W,pad,slope", [(64, 3, 20, 12, 0, 0.1), (512, 5, 13, 13, 1, 0.1), (128, 2, 26, 26, 1, 1.0)])
+def test_bn_plain_bwd_from_stored_activation(dev, C, B, H, W, pad, slope):
+    """mcamd_act_bwd_desc.act (bn_plain_bwd_act_kernel): the BatchNorm + LeakyReLU backward of a PLAIN block from the
+    fp16 activation the forward pass stored (hi plane of split storage, padded or shared-halo buffer, a channel slice of a
+    wider buffer) instead of the saved fp32 raw output: z = act > 0 ? act : act / slope, xhat = (z - beta) / gamma.
+    Against the fp32-y kernel on the same inputs (dY within 2e-3 -- the fp16 rounding of the activation -- dgamma / dbeta
+    within 1e-3) and against float64 autograd; a pruned filter (dy_keep 0) and a gamma == 0 channel (whose dgamma comes from
+    the saved y, as in the y kernel) included; with y = NULL that one dgamma is 0 and everything else is unchanged."""
+    gen = torch.Generator().manual_seed(11 + C)
+    M = B * H * W
+    y = (torch.randn(M, C, generator=gen) * 0.7 + 0.4).to(dev)                    # fp32 raw output (split-operand engines)
+    mean = y.mean(0)
+    invstd = 1.0 / torch.sqrt(y.var(0, unbiased=False) + 1e-5)
+    gamma = (torch.rand(C, generator=gen) + 0.5).to(dev)
+    gamma[3] = 0.0                                                                 # no xhat to recover from the activation
+    beta = (torch.randn(C, generator=gen) * 0.2).to(dev)
+    scale = (gamma * invstd).contiguous()
+    shift = (beta - mean * scale).contiguous()
+    keep = torch.ones(C, device=dev)
+    keep[7] = 0.0
+    g = (torch.randn(M, C, generator=gen) * 3).half().to(dev)
+    # the stored activation: the forward pass itself, two planes, into channels [32, 32 + C) of a wider buffer
+    ld = 2 * C + 64
+    abuf = ops.alloc_padded(B, H, W, ld, dev, pad=pad)
+    ops.bn_act_fwd(B, H, W, C, y.reshape(-1), C, 0, scale, shift, slope, L.DST_PLAIN, abuf, ld, 32, None, 0, 0,
+                   planes=2, dst_plane=C, dst_pad=pad)
+    res = []
+    for use_act in (False, True):
+        dy = ops.alloc_padded(B, H, W, C, dev, pad=pad)
+        dgm, dbt = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        kw = dict(act=abuf, act_ld=ld, act_choff=32, act_pad=pad) if use_act else {}
+        ops.bn_act_bwd(B, H, W, C, y.reshape(-1), C, 0, scale, shift, mean.contiguous(), invstd.contiguous(),
+                       slope, L.DST_PLAIN, g, C, 0, dy, C, 0, dgm, dbt, grad_scale=2.0, dy_keep=keep, dy_pad=pad, **kw)
+        res.append((ops.padded_view(dy, B, H, W, C)[:, 1:-1, 1:-1].float().cpu(), dgm.cpu(), dbt.cpu()))
+    (dy0, dg0, db0), (dy1, dg1, db1) = res
+    ok = torch.ones(C, dtype=torch.bool)
+    ok[3] = False
+    assert rel_l2(db1, db0) < 1e-5
+    assert rel_l2(dg1[ok], dg0[ok]) < 1e-3
+    assert abs(float(dg1[3] - dg0[3])) <= 1e-5 * abs(float(dg0[3]))       # gamma == 0: that thread read the saved y
+    assert rel_l2(dy1, dy0) < 2e-3
+    assert float(dy1[..., 7].abs().max()) == 0.0 and float(dy1[..., 3].abs().max()) == 0.0
+    dy = ops.alloc_padded(B, H, W, C, dev, pad=pad)
+    dgm, dbt = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    ops.bn_act_bwd(B, H, W, C, None, C, 0, scale, shift, mean.contiguous(), invstd.contiguous(), slope, L.DST_PLAIN, g, C, 0,
+                   dy, C, 0, dgm, dbt, grad_scale=2.0, dy_keep=keep, dy_pad=pad, act=abuf, act_ld=ld, act_choff=32, act_pad=pad)
+    assert float(dgm[3]) == 0.0 and torch.equal(dgm.cpu()[ok], dg1[ok]) and torch.equal(dbt.cpu(), db1)
+    assert torch.equal(ops.padded_view(dy, B, H, W, C)[:, 1:-1, 1:-1].float().cpu(), dy1)
+    # float64 autograd of BatchNorm (batch statistics given) + LeakyReLU on the same y
+    yd = y.double().cpu().requires_grad_(True)
+    gm, bt = gamma.double().cpu().requires_grad_(True), beta.double().cpu().requires_grad_(True)
+    z = F.batch_norm(yd, None, None, gm, bt, True, 0.0, 1e-5)
+    (F.leaky_relu(z, slope) * g.double().cpu()).sum().backward()
+    ref = (yd.grad * keep.double().cpu()).view(B, H, W, C) / 1.0
+    assert rel_l2(dy1.double() * 1.0, ref) < 3e-3
+    assert rel_l2(dg1[ok].double() * 2.0, gm.grad[ok]) < 2e-3 and rel_l2(db1.double() * 2.0, bt.grad) < 1e-4
+
+
 def test_bn_coeffs_eval(dev):
     C = 64
     gamma, beta = torch.rand(C) + 0.5, torch.randn(C)

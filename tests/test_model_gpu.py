@@ -118,6 +118,7 @@ def test_mini_train_fwd_bwd_vs_golden(dev):
     test_layerwise_teacher_forced checks."""
     gold = np.load(os.path.join(HERE, "golden", "mini_fwd_bwd.npz"))
     m, blocks, state = _mini_model(dev)
+    m.precision = "fp16"                 # the plain-operand throughput mode (the default, "mixed", is held to 1e-3 above)
     m.train()
     x, gout = torch.from_numpy(gold["x"]), torch.from_numpy(gold["gout"])
     out = m(x.to(dev))
@@ -149,6 +150,7 @@ def test_mini_masked_training_steps(dev):
     m.set_masks(masks)
     start = {n: p.detach().cpu().clone() for n, p in m.named_parameters()}
     opt = torch.optim.SGD(m.parameters(), lr=1e-3, momentum=0.9, dampening=0, weight_decay=0.0005 * 2)
+    m.precision = "fp16"                 # (the split-operand forward has its own, absolute-bar version of this test below)
     m.train()
     for step in range(2):
         out = m(torch.from_numpy(gold["x%d" % step]).to(dev))
@@ -234,6 +236,7 @@ def _teacher_forced(dev, cfg, B, seed, masked, hw=None, only=None, grad_scale=No
     x = torch.rand(B, 3, H, W, generator=g)
     m = nets.Darknet(cfg)
     m.load_state_dict(state)
+    m.precision = "fp16"       # every kernel of the plain-operand engine (compaction, folding, shared halo live there)
     m.to(dev).train()
     if grad_scale is not None:
         m.grad_scale = grad_scale
@@ -688,6 +691,7 @@ def test_yolov2_train_step_vs_oracle(dev):
     gout = torch.randn(2, 125, 13, 13, generator=g)
     m = nets.Darknet(YOLOV2_VOC_CFG)
     m.load_state_dict(state)
+    m.precision = "fp16"
     m.to(dev).train()
     out = m(x.to(dev))
     out.backward(gout.to(dev))
@@ -713,8 +717,9 @@ def test_yolov2_train_step_vs_oracle(dev):
         assert ge < 1.5 * gf + 5e-3, (name, ge, gf)
 
 
-@pytest.mark.parametrize("masks,B", [(None, 64), ("filter40", 32)], ids=["dense-b64", "filter40-b32"])
-def test_training_step_is_bit_reproducible(dev, masks, B):
+@pytest.mark.parametrize("masks,B,prec", [(None, 64, "fp16"), ("filter40", 32, "fp16"), (None, 64, "auto")],
+                         ids=["dense-b64", "filter40-b32", "dense-b64-default-precision"])
+def test_training_step_is_bit_reproducible(dev, masks, B, prec):
     """Every reduction of a training step has a fixed order (split-K slabs, BatchNorm slabs, the Gram and gradient slabs of
     the fused first block, the folded-weight sums) and no kernel uses floating-point atomics: the same step run three times
     -- weight gradients overlapped on the second stream, as in production -- gives bit-identical logits and gradients.
@@ -723,6 +728,7 @@ def test_training_step_is_bit_reproducible(dev, masks, B):
     blocks = O.parse_cfg(YOLOV2_VOC_CFG)
     m = nets.Darknet(YOLOV2_VOC_CFG)
     m.load_state_dict(O.init_state(blocks, seed=3))
+    m.precision = prec                   # "auto" = the training default, "mixed": split-operand forward, fused split first block
     m.to(dev).train()
     if masks:
         from modelcompression_amd.pruning.weightPruning.methods import quick_filter_prune
@@ -739,7 +745,8 @@ def test_training_step_is_bit_reproducible(dev, masks, B):
         out.float().mean().backward()
         runs.append((out.detach().clone(), m._last_flat_grad.clone()))
     eng = list(m._engines.values())[0]
-    assert eng.overlap_wgrad and eng.layers[0].fused_stem
+    assert eng.precision == ("fp16" if prec == "fp16" else "mixed")
+    assert eng.overlap_wgrad and (eng.layers[0].fused_stem if prec == "fp16" else eng.layers[0].stem_split)
     assert eng.use_plan and eng._bwd_plan is not None and eng._bwd_plan.launches > 60 and eng._fwd_plans[True].launches > 40
     if masks:
         assert any(lay.fold is not None for lay in eng.layers)
