@@ -290,8 +290,11 @@ def main():
                     help="mean = mean of the logits (the headline line); region = the real train.py step: RegionLoss on "
                          "synthetic boxes + the device-side overflow / non-finite policy (train.StepGuard), reference "
                          "train.py:214-235")
-    ap.add_argument("--no-tolerance-mode", action="store_true",
-                    help="skip the second timed leg (the 1e-3-compliant `mixed` training precision) and the parity check")
+    ap.add_argument("--precision", default="auto", choices=["auto", "mixed", "fp16"],
+                    help="operand precision of the TIMED step: auto = the drop-in's training default (`mixed`: split hi/lo "
+                         "operands, train-mode logits within north_star's 1e-3); fp16 = plain operands, the throughput opt-in")
+    ap.add_argument("--no-tolerance-mode", "--no-second-precision", dest="no_tolerance_mode", action="store_true",
+                    help="skip the second timed leg (the OTHER precision of {mixed, fp16}) and the parity check")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -340,6 +343,10 @@ def main():
     model.to(dev).train()
     if args.workload == "prune":
         return bench_prune(args, model, dev)
+    # the timed precision: the drop-in's default unless asked otherwise; the other one of {mixed, fp16} is the second leg
+    main_prec = "fp16" if args.precision == "fp16" else "mixed"
+    other_prec = "mixed" if main_prec == "fp16" else "fp16"
+    model.precision = args.precision
     B = args.batch
     wl_name = "dense (0% prune)"
     masks = None
@@ -499,7 +506,7 @@ def main():
 
     # ---- roofline of the dominant kernel, from a SEPARATE instrumented pass (the timed region above carries no events):
     # every conv launch bracketed by HIP events on the launch stream
-    eng = [e for e in model._engines.values() if e.precision == "fp16" and e.grad_scale == float(model.grad_scale)][0]
+    eng = [e for e in model._engines.values() if e.precision == main_prec and e.grad_scale == float(model.grad_scale)][0]
     # One instrumented step at a time, harvested before the next: at most one step's events are alive (round 3 kept all
     # 5 x 138 timing events until the end), the event objects are reused, and the garbage collector is kept out of the
     # pass (its pauses over the whole run are measured by `gc_watch` below and reported).  Per launch the MEDIAN over the
@@ -532,35 +539,46 @@ def main():
     per = {k: [median(v[0]) * len(v[0]), len(v[0]), v[1]] for k, v in per.items()}      # (median x n, n, layer): as the mean was
     tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
     rows = []
-    by_tile = {}     # igemm instance (BM, BN, BK) -> [ms, flop, launches]
+    by_tile = {}     # kernel instance (BM, BN, BK, kind, epilogue) -> [ms, algorithmic flop, launches, executed MFMA flop]
     for (tag, li), (ms, n, lay) in sorted(per.items(), key=lambda kv: (kv[0][1], kv[0][0])):
-        fl = eng.conv_flops(lay)
+        fl = eng.conv_flops(lay)                       # ALGORITHMIC flops: 2 M Cout Cin k^2 of the reference's convolution
         avg = ms / n
-        tile = ops.tile_info(lay.geom_act, dgrad=(tag == "dgrad")) if tag != "wgrad" else None   # (the instrumented pass runs every launch alone)
+        # a split-operand forward launch multiplies the K-concatenated problem: `level` MFMA products per algorithmic one
+        level = lay.level if (tag == "fwd" and eng.precise) else 1
+        tile = None
+        if tag != "wgrad" and not (li == 0 and (lay.fused_stem or getattr(lay, "stem_split", False))):
+            g_ = lay.geom_f if (tag == "fwd" and eng.precise) else lay.geom_act
+            epi = (1 if lay.is_last else (3 if eng.precise else 0)) if tag == "fwd" else 0
+            tile = ops.tile_info(g_, dgrad=(tag == "dgrad")) + (epi,)   # (the instrumented pass runs every launch alone)
         tot[tag][0] += avg
         tot[tag][1] += fl
-        rows.append("%-6s conv%-2d %4dx%-4d cin %4d cout %4d k%d  %8.3f ms  %8.1f TFLOP/s  tile %s" % (
-            tag, li + 1, lay.H, lay.W, lay.cin, lay.cout, lay.k, avg, fl / avg / 1e9, tile))
+        rows.append("%-6s conv%-2d %4dx%-4d cin %4d cout %4d k%d  %8.3f ms  %8.1f TFLOP/s%s  tile %s" % (
+            tag, li + 1, lay.H, lay.W, lay.cin, lay.cout, lay.k, avg, fl / avg / 1e9,
+            (" (x%d MFMA products: %.1f executed)" % (level, level * fl / avg / 1e9)) if level > 1 else "", tile))
         if tile is not None:
-            b = by_tile.setdefault(tile, [0.0, 0.0, 0])
+            b = by_tile.setdefault(tile, [0.0, 0.0, 0, 0.0])
             b[0] += ms
             b[1] += fl * n
             b[2] += n
-    # the dominant kernel = the igemm instance with the largest total time
+            b[3] += level * fl * n
+    # the dominant kernel = the implicit-GEMM instance with the largest total time
     dom_tile = max(by_tile, key=lambda t: by_tile[t][0])
-    dom_ms, dom_flop, dom_n = by_tile[dom_tile]
+    dom_ms, dom_flop, dom_n, dom_exec = by_tile[dom_tile]
     achieved = dom_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    executed = dom_exec / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process; they are
     # collected by tools/collect_profiles.sh on the same command (FETCH_SIZE and WRITE_SIZE in separate
     # rocprofv3 passes, FETCH_SIZE doubled per the gfx950 correction) and committed under profiles/.
-    traffic = None
+    traffic = traffic_source = None
     tfile = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
-            want = {2: "void igemm_pp_kernel<0, %d," % dom_tile[0]}.get(dom_tile[3], "void igemm_kernel<%d, %d," % dom_tile[:2])
+            want = {2: "void igemm_pp_kernel<%d, %d, %d," % (dom_tile[4], dom_tile[0], dom_tile[1])}.get(
+                dom_tile[3], "void igemm_kernel<%d, %d," % dom_tile[:2])
             if tj["kernel"].startswith(want):
                 traffic = round(tj["hbm_bytes_per_launch"])
+                traffic_source = tj.get("source", "profiles/dominant_kernel_traffic.json")
         except Exception:
             traffic = None
     step_ms = dt / args.steps * 1e3
@@ -571,18 +589,30 @@ def main():
                 f.write("TOTAL %-6s %8.3f ms/step  %8.1f TFLOP/s\n" % (tag, ms, fl / ms / 1e9 if ms else 0))
             f.write("step %.3f ms (uninstrumented); conv kernels %.3f ms\n" % (step_ms, sum(v[0] for v in tot.values())))
 
-    # ---- second timed leg: the training precision that meets north_star's 1e-3 on the region-layer logits ("mixed":
-    # split hi/lo operands on all but the costliest blocks, engine.py), same step, same batch, same barriers
-    tol = None
+    # ---- second timed leg: the OTHER precision of {mixed, fp16} -- same step, same batch, same barriers.  `mixed` (split
+    # hi/lo operands on all but the costliest blocks, engine.py) meets north_star's 1e-3 on the region-layer logits; plain
+    # `fp16` is the throughput opt-in
+    def leg_info(prec, seconds):
+        e_ = [e for e in model._engines.values() if e.precision == prec][-1]
+        d = {"precision": prec, "images_per_s": round(world * B * args.steps / seconds, 2),
+             "ms_per_step": round(seconds / args.steps * 1e3, 3)}
+        if prec == "mixed":
+            d["plain_fp16_blocks"] = [l.li + 1 for l in e_.layers if l.level == 1]
+            d["note"] = ("forward convolutions on split hi/lo fp16 operands (3 MFMA products per multiply, fp32 raw outputs) "
+                         "except the listed blocks; the first block fused on split operands; backward on plain fp16 operands")
+        else:
+            d["note"] = "plain fp16 MFMA operands everywhere: its train-mode logits do NOT meet 1e-3 (see `parity`)"
+        return d
+    legs = {main_prec: leg_info(main_prec, dt)}
     if not args.no_tolerance_mode:
-        model.precision = "mixed"
+        model.precision = other_prec
         for _ in range(max(2, min(args.warmup, 3))):
             step()
         if guard is not None:
             guard.finish()
         gc.collect()
         fence()
-        region[0] = "timed_tolerance_mode"
+        region[0] = "timed_second_precision"
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -593,14 +623,9 @@ def main():
             t = torch.tensor([dt_m], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_m = float(t.item())
-        assert not model.grad_overflowed(), "a scaled gradient saturated the fp16 range in the mixed-precision run"
-        eng_m = [e for e in model._engines.values() if e.precision == "mixed"][-1]
-        tol = {"precision": "mixed", "images_per_s": round(world * B * args.steps / dt_m, 2),
-               "ms_per_step": round(dt_m / args.steps * 1e3, 3),
-               "plain_fp16_blocks": [l.li + 1 for l in eng_m.layers if l.level == 1],
-               "note": "forward convolutions on split hi/lo fp16 operands (3 MFMA products per multiply, fp32 raw outputs) "
-                       "except the listed blocks; backward on plain fp16 operands"}
-        model.precision = "auto"
+        assert not model.grad_overflowed(), "a scaled gradient saturated the fp16 range in the second-precision run"
+        legs[other_prec] = leg_info(other_prec, dt_m)
+        model.precision = args.precision
     # ---- parity of what was timed: training-mode logits (batch statistics) of both precisions against the fp32 oracle
     # on the SAME weights and the same batch (rank 0, N = 1; the oracle is the checker, ~5 s of host time)
     parity = None
@@ -620,9 +645,9 @@ def main():
             with torch.no_grad():
                 got = model(x).cpu()
             parity["train_logits_rel_l2_" + prec] = float("%.3e" % ((got.double() - ref.double()).norm() / ref.double().norm()))
-        model.precision = "auto"
-        if tol is not None:
-            tol["train_logits_rel_l2"] = parity["train_logits_rel_l2_mixed"]
+        model.precision = args.precision
+        for prec in legs:
+            legs[prec]["train_logits_rel_l2"] = parity["train_logits_rel_l2_" + prec]
     if rank != 0:
         return
     value = world * B * args.steps / dt
@@ -635,9 +660,14 @@ def main():
                    "global_batch": world * B, "input": "3x416x416", "parallelism": "dp%d" % world,
                    "loss": ("RegionLoss on synthetic boxes + train.StepGuard (the train.py step)" if guard is not None
                             else "mean of the logits"),
-                   "precision": "fp16 (plain fp16 MFMA operands: the throughput mode; its train-mode logits do NOT meet "
-                                "north_star's 1e-3, see `parity`; `tolerance_mode` is the precision that does)",
-                   "tolerance_mode": tol,
+                   "precision": ("mixed (the drop-in's training default: forward convolutions on split hi/lo fp16 operands "
+                                 "except the blocks listed in `tolerance_mode`, train-mode logits within north_star's 1e-3, see "
+                                 "`parity`; `throughput_mode` = plain fp16 operands, the explicit opt-in)") if main_prec == "mixed" else
+                                ("fp16 (plain fp16 MFMA operands: the throughput opt-in; its train-mode logits do NOT meet "
+                                 "north_star's 1e-3, see `parity`; `tolerance_mode` is the default precision, which does)"),
+                   "timed_precision": main_prec,
+                   "tolerance_mode": legs.get("mixed"),
+                   "throughput_mode": legs.get("fp16"),
                    "grad_scale": model.grad_scale,
                    # engine.py _get_side_stream: the weight-gradient stream was PROBED to run beside the launch stream
                    # (None: overlap off or probe disabled; False: no concurrent stream found, the step is serialised)
@@ -647,11 +677,16 @@ def main():
                    "conv_kernel_ms_per_step": {k: round(v[0], 3) for k, v in tot.items()},
                    "conv_kernel_tflops": {k: round(v[1] / v[0] / 1e9, 1) if v[0] else 0.0 for k, v in tot.items()}},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": traffic,
+                     "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_gflop_per_launch": round(dom_flop / max(dom_n, 1) / 1e9, 2),
-                     "kernel": ("igemm_pp_kernel<0,%d,%d,16> %dx%dx%d ping-pong (conv fwd + dgrad launches of that instance)" % (
-                                    dom_tile[:2] + dom_tile[:3]) if dom_tile[3] == 2 else
-                                "igemm_kernel<%d,%d,..,%d,2,0> (conv fwd + dgrad launches of that instance)" % dom_tile[:3]),
+                     # split-operand launches execute 3 MFMA products per algorithmic multiply: the rate the matrix cores
+                     # actually ran at (achieved counts the reference's 2 M N K only, as the contract asks)
+                     "mfma_tflops_executed": round(executed, 1), "mfma_frac_executed": round(executed / PEAK_FP16_TFLOPS, 4),
+                     "kernel": ("igemm_pp_kernel<%d,%d,%d,16> %dx%dx%d ping-pong (%s launches of that instance)" % (
+                                    (dom_tile[4],) + dom_tile[:2] + dom_tile[:3] +
+                                    ("split-operand conv forward, fp32 raw output" if dom_tile[4] == 3 else "conv fwd + dgrad",))
+                                if dom_tile[3] == 2 else
+                                "igemm_kernel<%d,%d,..,%d,2,%d> (conv launches of that instance)" % (dom_tile[:3] + (dom_tile[4],))),
                      "launches_per_step": dom_n // nprof,
                      "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4),
                      "measured": "HIP events around every launch in %d extra steps after the timed region; per launch the "

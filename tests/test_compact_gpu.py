@@ -26,6 +26,7 @@ def _model(cfg, dev, seed, perc):
     state = O.init_state(blocks, seed=seed)
     m = nets.Darknet(cfg)
     m.load_state_dict(state)
+    m.precision = "fp16"       # filter compaction and dead-input folding live in the plain-operand engine
     m.to(dev)
     masks = quick_filter_prune(m, perc)
     m.set_masks(masks)
