@@ -609,7 +609,7 @@ class Engine:
                 if lay.wd is not None:
                     lay.wd.zero_()
         if self.precise:
-            self._pack_split()
+            self._pack_split(training)
             self._packed_sig = sig
             self.model._weights_dirty = False
             return
@@ -678,7 +678,7 @@ class Engine:
         self._packed_sig = sig
         self.model._weights_dirty = False
 
-    def _pack_split(self):
+    def _pack_split(self, training=False):
         """Packings of the split-operand modes: forward = fp16 of [w_hi | w_hi | w_lo] along the input channels
         (w_hi = fp16(w * mask), w_lo = fp16(w * mask - w_hi)), matching the [x_hi | x_lo | x_hi] activation planes;
         dgrad = the plain fp16 packing (the backward pass multiplies plain operands).  One launch for all layers: the
@@ -701,6 +701,9 @@ class Engine:
                                  dst_fwd=lay.wp, dst_dgrad=lay.wd, split=lay.level == 3))
             self._pack_table = ops.pack_table(jobs, self.device) if jobs else None
             self._pack_key = key
+        # (on the second stream under the fused split-operand first block, together with that block's Gram pass: measured
+        # 12.951 vs 12.974 ms per step, i.e. nothing -- the first block's own passes are HBM-bound too; not kept)
+        self._pack_on_side = False
         if self._pack_table is not None:
             ops.pack_many(*self._pack_table)
         for lay in self.layers:

@@ -550,6 +550,14 @@ def test_layerwise_teacher_forced_yolov2_filter40(dev):
     _teacher_forced(dev, YOLOV2_VOC_CFG, 8, 12, masked="filter40", grad_scale=16.0)
 
 
+def test_layerwise_teacher_forced_yolov2_filter40_b64_head(dev):
+    """The compacted and folded launches of the EARLY blocks at the bench's batch (conv1-8 with
+    compaction had only run at B=8): the 104x104 / 52x52 layers keep 1-66 filters at 40 %, their consumers run on a
+    handful of input channels + the ones-channel, BatchNorm passes narrowed to the kept channels -- 11 M-pixel reductions
+    with ragged channel counts, every launch against float64 `F.conv2d(x, w * mask)` on identical inputs."""
+    _teacher_forced(dev, YOLOV2_VOC_CFG, 64, 12, masked="filter40", grad_scale=16.0, only=set(range(1, 9)))
+
+
 def test_layerwise_teacher_forced_yolov2_filter60_b64_tail(dev):
     """Compacted launches at the bench's batch on the 26x26 / 13x13 blocks (ragged kept counts on the ping-pong and
     192-row tiles, the 9-tap weight gradient with row / column maps)."""
