@@ -363,8 +363,7 @@ def main():
     if args.workload == "slim60":
         return bench_slim(args, model, dev, rank)
     # same update rule as train.py:144-147; torch's fused multi-tensor implementation (one kernel per dtype/device)
-    sgd_kw = {"fused": True} if os.environ.get("MCAMD_SGD_FUSED", "1") == "1" else {}
-    opt = torch.optim.SGD(model.parameters(), lr=1e-5, momentum=0.9, dampening=0, weight_decay=0.0005 * B, **sgd_kw)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-5, momentum=0.9, dampening=0, weight_decay=0.0005 * B, fused=True)
     reducer = None
     dp_on = world > 1 or (dp.rehearsal() and dist.is_initialized())     # MCAMD_DP_REHEARSE=1: one-rank RCCL rehearsal
     if dp_on:

@@ -457,7 +457,7 @@ extern "C" int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int
     }
     mcamd_igemm_tile((long long)g->B * g->H * g->W, dgrad ? g->cin : g->cout, dgrad ? cout_p_of(g) : cin_tap_of(g),
                      dgrad ? g->ksize * g->ksize * cout_p_of(g) : ntaps_of(g) * cin_tap_of(g), out,
-                     dgrad == 2 && MCAMD_ENV_INT("MCAMD_CONCURRENT_TILES", 1) != 0);
+                     dgrad == 2);
     return MCAMD_OK;
 }
 

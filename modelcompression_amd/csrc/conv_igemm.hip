@@ -57,7 +57,7 @@ void igemm_kernel(IgemmArgs a) {
     // XCD-aware order.  Work items (N tile, persistent M slot) are numbered N-major; blocks are dealt
     // round-robin to the 8 XCDs, so XCD x takes the contiguous chunk [x*chunk, (x+1)*chunk): about one
     // weight (B) tile per XCD stays resident in its 4 MB L2 while the activation tiles stream through.
-    // MCAMD_XCD_ORDER=1 selects the other orientation (all N tiles of an M slot on one XCD).
+    // a.xcd_order = 1 (what the launchers set) is the other orientation: all N tiles of an M slot on one XCD.
     int nt, pslot;
     if (a.xcd_order == 0) {
         const int total_items = a.num_ntiles * a.num_pslots;
@@ -362,14 +362,13 @@ static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot, bool raw_epi
         if (pp && ktot >= 256 && n >= 128 && M >= 256) {
             bool use = pp == 2;
             int bm = 256, bn = 256;
-            // K >= 1152 for any layer.  (3x3 layers from K = 576, MCAMD_PP_MINK=512, looked like a gain at first -- conv3/5
+            // K >= 1152 for any layer.  (3x3 layers from K = 576 looked like a gain at first -- conv3/5
             // forward 0.183 -> 0.176 ms in one run -- but measured back to back on one box the whole step is 0.5 % slower with
             // it: 9.846 / 9.836 vs 9.800 / 9.782 ms, conv3/5 forward 0.186 vs 0.174 ms in the event pass.)
-            // (MCAMD_PP_MINK_1X1=512 sends the 1x1 layers with K >= 512 here too: conv10/12 forward 37 -> 32 us, conv15/17
+            // (The 1x1 layers with K >= 512 here too: conv10/12 forward 37 -> 32 us, conv15/17
             // dgrad 30 -> 25 us, 20 us = 0.2 % of a step in all; K = 256 and the K = 576 3x3 layers measured equal or
             // slower.  Off by default: these 30 us launches are latency-bound whatever the tile.)
-            if (pp == 1 && (ktot >= 1152 || (ktot == cin_tap && ktot >= MCAMD_ENV_INT("MCAMD_PP_MINK_1X1", 1152)) ||
-                            (ktot >= MCAMD_ENV_INT("MCAMD_PP_MINK", 1152) && ktot == 9 * cin_tap))) {
+            if (pp == 1 && ktot >= 1152) {
                 // Measured (profiles/): per busy CU the ping-pong tile is ~1.27x the 192x128 tile, but
                 // it runs ONE workgroup per CU, so it only pays when its tiles fill the 256 CUs well: 256 or 192 rows,
                 // 256 or 128 columns (128 columns stage 1.3x the bytes per flop: costed at 0.8 of the 256-column rate),
@@ -421,7 +420,7 @@ static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot, bool raw_epi
     // Few tiles (the 13x13 layers at the per-GPU batch of BASELINE configs[3], B = 32: M = 5 408 -> 43 x 4 tiles of 128 x 128
     // for N = 512, 172 workgroups on 256 CUs): 64-column tiles double the workgroups at 2/3 of the per-tile rate
     // (dgrad total at B = 32: 1.69 -> 1.65 ms per step, 6.235 -> 6.22 ms per step; nothing changes at B = 64)
-    if (t.bn == 128 && n % 64 == 0 && MCAMD_ENV_INT("MCAMD_NARROW_FILL", 1)) {
+    if (t.bn == 128 && n % 64 == 0) {
         const long long t128 = ((M + 127) / 128) * ((n + 127) / 128);
         if (t128 < 256 && 2 * t128 <= 512) t.bn = 64;
     }
@@ -429,14 +428,13 @@ static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot, bool raw_epi
     t.bk = (want_bk == 64 && cin_tap % 64 == 0) ? 64 : 32;
     // Tile quantisation: 2 workgroups per CU = 512 slots.  A 192-row tile (wave tile 96x64) often turns
     // a nearly empty last round into none (13x13 layers at B=64: 680 tiles -> 456); time ~ rounds x BM.
-    if (t.bm == 128 && t.bn == 128 && t.bk == 64 && MCAMD_ENV_INT("MCAMD_BM192", 1) &&
-        (ktot >= MCAMD_ENV_INT("MCAMD_BM192_MINK", 2048) || MCAMD_ENV_INT("MCAMD_BM192", 1) == 2)) {   // pays only when the K loop is long
+    if (t.bm == 128 && t.bn == 128 && t.bk == 64 && ktot >= 2048) {   // pays only when the K loop is long
         const long long nt = (n + 127) / 128;
         const long long t128 = ((M + 127) / 128) * nt, t192 = ((M + 191) / 192) * nt;
         const long long cost128 = ((t128 + 511) / 512) * 128, cost192 = ((t192 + 511) / 512) * 192;
         // ties go to the 192-row tile: fewer, fuller rounds and 20 % less staged bytes per flop (26x26 forward, K = 2304:
         // 0.127 vs 0.134 ms)
-        if (cost192 <= cost128 || MCAMD_ENV_INT("MCAMD_BM192", 1) == 2) t.bm = 192;
+        if (cost192 <= cost128) t.bm = 192;
     }
     return t;
 }
@@ -454,7 +452,7 @@ int mcamd_igemm_rows(long long M, int n, int cin_tap, int ktot, bool raw_epilogu
     int ntiles = (n + t.bn - 1) / t.bn;
     int mtiles = igemm_mtiles(M, t.bm);
     if (t.kind == 4) return mcamd_small3x3_rows(M);
-    int target = t.kind == 2 ? 256 : MCAMD_ENV_INT("MCAMD_IGEMM_WGS", 2048);   // ping-pong: one workgroup per CU, persistent
+    int target = t.kind == 2 ? 256 : 2048;   // ping-pong: one workgroup per CU, persistent
     int p = target / ntiles;
     if (p < 1) p = 1;
     if (p > mtiles) p = mtiles;
@@ -483,7 +481,7 @@ static void launch_one(const IgemmArgs& a, int rows, int ntiles, hipStream_t st)
 // a.* geometry fields must be filled by the caller; picks the tile and launches.
 int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st) {
     if (mcamd_win3x3_ok(a)) return mcamd_win3x3_launch(a, st);   // conv2 dgrad: rolling LDS window (conv_win.hip)
-    const bool conc = a.concurrent != 0 && MCAMD_ENV_INT("MCAMD_CONCURRENT_TILES", 1) != 0;
+    const bool conc = a.concurrent != 0;
     TileCfg t = pick_tile(a.M, a.N, a.cin_tap, a.ktot, a.mode == MCAMD_EPI_RAW_F16, conc);   // stats slabs only exist with RAW
     if (t.kind == 4) return mcamd_small3x3_launch(a, st);
     if (a.cin_tap % t.bk != 0 || a.ktot % t.bk != 0) {
@@ -495,9 +493,9 @@ int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st) {
     int rows = mcamd_igemm_rows(a.M, a.N, a.cin_tap, a.ktot, a.mode == MCAMD_EPI_RAW_F16, conc);
     a.num_pslots = rows;
     a.num_ntiles = ntiles;
-    a.xcd_order = MCAMD_ENV_INT("MCAMD_XCD_ORDER", 1);
+    a.xcd_order = 1;
     if (t.kind == 2) return mcamd_igemm_pp_launch(a, t.bm, t.bn, rows, ntiles, st);
-    const int stages = MCAMD_ENV_INT("MCAMD_STAGES", t.bk == 32 ? 3 : 2);
+    const int stages = t.bk == 32 ? 3 : 2;
 #define I_CASE(BN_, WM_, WN_, BK_, ST_)                              \
     if (!done && t.bm == 128 && t.bn == BN_ && t.bk == BK_ && stages == ST_) { \
         launch_one<128, BN_, WM_, WN_, BK_, ST_>(a, rows, ntiles, st); \

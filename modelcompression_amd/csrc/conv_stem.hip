@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs a) {
 }
 
 bool mcamd_stem_direct_ok(int stem, int cout, int mode) {
-    return MCAMD_ENV_INT("MCAMD_STEM_DIRECT", 1) != 0 && stem && mode == MCAMD_EPI_RAW_F16 && (cout == 32 || cout == 64);
+    return stem && mode == MCAMD_EPI_RAW_F16 && (cout == 32 || cout == 64);
 }
 
 int mcamd_stem_rows(long long M) {

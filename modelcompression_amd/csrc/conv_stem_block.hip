@@ -758,8 +758,7 @@ extern "C" int mcamd_stem_block_fwd(const mcamd_stem_block_desc* d, void* worksp
         g.nunits = (long long)d->B * d->H * g.Wb;
         g.slab = (float*)(ws + c.gram_slab);
         long long want = (g.nunits + 31) / 32;    // >= one batch of 4 steps per wave
-        const int e_gw = MCAMD_ENV_INT("MCAMD_STEM_GRAM_WGS", 512);     // tuning switch (<= kGramWgs)
-        const int gmax = e_gw > 0 && e_gw <= kGramWgs ? e_gw : 512;   // 2 workgroups per CU: 223 vs 239 us
+        const int gmax = kGramWgs;   // 2 workgroups per CU: 223 vs 239 us
         const int grid = (int)(want < gmax ? (want < 1 ? 1 : want) : gmax);
         hipLaunchKernelGGL(stem_gram_kernel, dim3(grid), dim3(512), 0, st, g);
         MCAMD_LAUNCH_CHECK("stem_gram");
@@ -776,16 +775,13 @@ extern "C" int mcamd_stem_block_fwd(const mcamd_stem_block_desc* d, void* worksp
     a.nunits = (long long)d->B * a.H2 * a.Wb;
     long long want = (a.nunits + 7) / 8;          // >= one pass of 2 units per wave
     const int grid = (int)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
-    const int un = MCAMD_ENV_INT("MCAMD_STEM_FWD_UN", 4);   // tuning switch
     if (split) {
         if (d->planes == 3) hipLaunchKernelGGL((stem_block_fwd_kernel<2, 3, true>), dim3(grid), dim3(256), 0, st, a);
         else if (d->planes == 2) hipLaunchKernelGGL((stem_block_fwd_kernel<2, 2, true>), dim3(grid), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((stem_block_fwd_kernel<2, 1, true>), dim3(grid), dim3(256), 0, st, a);
     } else if (d->planes == 3) hipLaunchKernelGGL((stem_block_fwd_kernel<2, 3>), dim3(grid), dim3(256), 0, st, a);
     else if (d->planes == 2) hipLaunchKernelGGL((stem_block_fwd_kernel<2, 2>), dim3(grid), dim3(256), 0, st, a);
-    else if (un == 4) hipLaunchKernelGGL((stem_block_fwd_kernel<4, 1>), dim3(grid), dim3(256), 0, st, a);
-    else if (un == 1) hipLaunchKernelGGL((stem_block_fwd_kernel<1, 1>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((stem_block_fwd_kernel<2, 1>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((stem_block_fwd_kernel<4, 1>), dim3(grid), dim3(256), 0, st, a);   // 4 units in flight per wave (1 / 2 / 4: 66 / 62 / 60 us)
     MCAMD_LAUNCH_CHECK("stem_block_fwd");
     return MCAMD_OK;
 }

@@ -743,8 +743,8 @@ static int pick_taps(int tmo, int tnc, int ntaps) {
 }
 
 static int pick_kp(int tmo, int tnc, int taps) {
-    if (tmo == 128 && tnc == 128 && taps == 1) return MCAMD_ENV_INT("MCAMD_WGRAD_KP_BIG", 32);
-    const int budget = MCAMD_ENV_INT("MCAMD_WGRAD_STAGE_KB", 24) * 1024;
+    if (tmo == 128 && tnc == 128 && taps == 1) return 32;
+    const int budget = 24 * 1024;
     for (int kp = 128; kp > 32; kp /= 2)
         if (kp * 2 * (tmo + taps * tnc) <= budget) return kp;
     return 32;
@@ -764,7 +764,7 @@ static WgradPlan wgrad9_plan(long long P, int cout, int cin_tap, int W, int pitc
     // workgroups still fit the LDS; the big-image layers (window of 64 + 2(W+3) rows) stay at 32
     p.kp = 32;
     {
-        const int want = MCAMD_ENV_INT("MCAMD_WGRAD9_KP", 64);   // 128 (13x13 layers only) measured 1.8x SLOWER
+        const int want = 64;   // 128 (13x13 layers only) measured 1.8x SLOWER
         for (int kp = 64; kp <= want && kp <= 128; kp *= 2)
             if (2 * (size_t)(kp + kp + 2 * wgrad9_S(pitch)) * 128 <= 72 * 1024) p.kp = kp;   // two workgroups per CU: 2 x 72 KB
     }
@@ -787,8 +787,8 @@ static WgradPlan wgrad9_plan(long long P, int cout, int cin_tap, int W, int pitc
     }
     long long tiles = (long long)p.n_otiles * p.n_ctiles;
     long long nsteps = (P + 31) / 32;   // in 32-pixel units
-    const long long slots = wide ? MCAMD_ENV_INT("MCAMD_WGRAD9W_SLOTS", 256) : MCAMD_ENV_INT("MCAMD_WGRAD9_SLOTS", 512);
-    long long cap = MCAMD_ENV_INT("MCAMD_WGRAD9_WGS", 2048) / tiles;
+    const long long slots = wide ? 256 : 512;
+    long long cap = 2048 / tiles;
     if (cap < 1) cap = 1;
     if (cap > nsteps / 8) cap = nsteps / 8 > 0 ? nsteps / 8 : 1;
     long long ns = 1;
@@ -812,7 +812,7 @@ static WgradPlan wgrad9_plan(long long P, int cout, int cin_tap, int W, int pitc
 
 bool mcamd_wgrad_use9(int ksize, int stem, int cout, int cin_tap, int W) {
     return ksize == 3 && !stem && cin_tap % 64 == 0 && cout % 32 == 0 && round_up_int(cout, 64) == round_up_int(cout, 32) &&
-           W <= MCAMD_ENV_INT("MCAMD_WGRAD9_MAXW", 208) && MCAMD_ENV_INT("MCAMD_WGRAD9", 1);
+           W <= 208 && MCAMD_ENV_INT("MCAMD_WGRAD9", 1);
 }
 
 WgradPlan mcamd_wgrad_plan9(long long P, int cout, int cin_tap, int W, int pitch, int B) { return wgrad9_plan(P, cout, cin_tap, W, pitch, B); }
@@ -843,7 +843,7 @@ int mcamd_wgrad9_launch(const WgradArgs& w, const WgradPlan& p, int pitch, long 
     const int grid = round_up_int(p.n_otiles * p.n_ctiles * p.nsplit, 8);
     if (p.nine == 2) {
         const size_t stage = (size_t)64 * 256 + (size_t)(64 + 2 * a.S) * 128;
-        const int ns = 3 * stage <= 160 * 1024 && MCAMD_ENV_INT("MCAMD_WGRAD9W_NS", 3) >= 3 ? 3 : 2;
+        const int ns = 3 * stage <= 160 * 1024 ? 3 : 2;
         MCAMD_LDS_OPT_IN((wgrad9w_kernel<64, 2>), 160 * 1024);
         MCAMD_LDS_OPT_IN((wgrad9w_kernel<64, 3>), 160 * 1024);
         if (ns == 3) hipLaunchKernelGGL((wgrad9w_kernel<64, 3>), dim3(grid), dim3(512), 3 * stage, st, a);
@@ -878,10 +878,10 @@ WgradPlan mcamd_wgrad_plan(long long M, int cout, int cin_tap, int ntaps) {
     long long tiles = (long long)p.n_otiles * p.n_tapgroups * p.n_ctiles;
     // Pixel splits: fill whole rounds of the machine.  `slots` workgroups run at once (3 per CU at the
     // default 48 KB of LDS); time ~ rounds(ns) / ns, plus the slab traffic that grows with ns.
-    const long long slots = MCAMD_ENV_INT("MCAMD_WGRAD_SLOTS", 768);
+    const long long slots = 768;
     long long max_by_work = (M + 8 * p.kp - 1) / (8 * p.kp);  // at least 8 steps per split
     if (max_by_work < 1) max_by_work = 1;
-    long long cap = MCAMD_ENV_INT("MCAMD_WGRAD_WGS", 3072) / tiles;
+    long long cap = 3072 / tiles;
     if (cap < 1) cap = 1;
     if (cap > max_by_work) cap = max_by_work;
     long long ns = 1;

@@ -145,7 +145,6 @@ __global__ __launch_bounds__(256) void wgrad_stem_kernel(WgradArgs a) {
 }
 
 bool mcamd_wgrad_stem_ok(int stem, int cout, int W, long long M) {
-    if (MCAMD_ENV_INT("MCAMD_WGRAD_STEM", 1) == 0) return false;
     return stem && cout == 32 && W % 32 == 0 && M >= 4096;
 }
 
@@ -328,7 +327,6 @@ __global__ __launch_bounds__(256, 1) void wgrad_win_kernel(WgradArgs a) {
 }
 
 bool mcamd_wgrad_win_ok(int ksize, int stem, int cout, int cin_tap, int W, long long M) {
-    if (MCAMD_ENV_INT("MCAMD_WGRAD_WIN", 1) == 0) return false;
     return ksize == 3 && !stem && cin_tap == 32 && round_up_int(cout, 32) <= 64 && W % 16 == 0 && M >= 4096;
 }
 

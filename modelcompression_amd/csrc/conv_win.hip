@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, 1) void win3x3_kernel(IgemmArgs a, int seg_row
 }
 
 // dgrad-shaped problems: 3x3, 64 padded input channels, <= 32 outputs, raw fp16 epilogue without statistics
-static bool win_enabled() { return MCAMD_ENV_INT("MCAMD_WIN3X3", 1) != 0; }
+static bool win_enabled() { return true; }
 
 bool mcamd_win3x3_ok(const IgemmArgs& a) {
     if (!win_enabled()) return false;
@@ -202,7 +202,7 @@ int mcamd_win3x3_launch(const IgemmArgs& a, hipStream_t st) {
     // prologue).  Pick the segment length whose units fill whole rounds of the 1024 waves (208 rows, 64 images, 7
     // strips: 13 rows -> exactly 7 units per wave, 0.150 ms; 16 rows -> 5.7, 0.165 ms).
     const long long runners = 1024;
-    int want = MCAMD_ENV_INT("MCAMD_WIN3X3_SEG", 0);
+    int want = 0;
     if (want <= 0) {
         want = 0;
         const long long per_row_units = (long long)(a.M / (a.H * a.W)) * nstrips;

@@ -76,17 +76,16 @@ def init_from_env(backend=None):
         local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
         torch.cuda.set_device(local)
         kwargs["device_id"] = torch.device("cuda", local)
-        if os.environ.get("MCAMD_DP_HIPRIO", "1") == "1":
-            # RCCL's kernels on a HIGH-priority stream: HIP gives priority streams hardware queues of their own, so the
-            # collectives can never land on the queue of the launch stream or of the weight-gradient stream and be
-            # serialised with the backward pass they are supposed to run under (engine.py _get_side_stream found
-            # exactly that collision between two normal-priority streams)
-            try:
-                opts = dist.ProcessGroupNCCL.Options()
-                opts.is_high_priority_stream = True
-                kwargs["pg_options"] = opts
-            except AttributeError:
-                pass
+        # RCCL's kernels on a HIGH-priority stream: HIP gives priority streams hardware queues of their own, so the
+        # collectives can never land on the queue of the launch stream or of the weight-gradient stream and be
+        # serialised with the backward pass they are supposed to run under (engine.py _get_side_stream found
+        # exactly that collision between two normal-priority streams)
+        try:
+            opts = dist.ProcessGroupNCCL.Options()
+            opts.is_high_priority_stream = True
+            kwargs["pg_options"] = opts
+        except AttributeError:
+            pass
     dist.init_process_group(backend=backend, **kwargs)
     return dist.get_rank(), dist.get_world_size()
 

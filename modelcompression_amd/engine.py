@@ -80,12 +80,10 @@ TRAIN_GAIN = 1.1
 
 
 def _probe_side_stream(device, tries=8):
-    """(stream, concurrent): see Engine._get_side_stream.  MCAMD_SIDE_PROBE=0 takes the first stream unprobed.
+    """(stream, concurrent): see Engine._get_side_stream.
     The decision is taken from DEVICE timestamps (the candidate's kernel ended before the launch stream's burst did), not
     from a host-side query, and the ranks of one node take turns (an advisory file lock): eight processes starting at
     once on a busy host cannot turn each other's probe into a false "not concurrent" (VERDICT r03 item 5)."""
-    if os.environ.get("MCAMD_SIDE_PROBE", "1") != "1":
-        return torch.cuda.Stream(device), None
     lock = None
     try:
         import fcntl
@@ -151,7 +149,7 @@ class Engine:
         # timing passes do that, bench.py)
         self.overlap_wgrad = os.environ.get("MCAMD_OVERLAP_WGRAD", "1") == "1"
         # every switch is read here, once per engine -- never inside a step
-        self.wgrad_chunk = max(1, int(os.environ.get("MCAMD_WGRAD_CHUNK", "1")))
+        self.wgrad_chunk = 1          # blocks per hand-over of weight gradients to the second stream (1-3 measured equal, 4+ slower)
         # launch plans (csrc/plan.hip): the layer walk of forward / backward is RECORDED once and replayed with one library
         # call per segment instead of one ctypes call per kernel launch (MCAMD_PLAN=0: the per-launch path; it is also what
         # a per-kernel timing pass uses).  Plans hold raw pointers: `_plan_epoch` counts re-plannings of the channel layout,
@@ -160,10 +158,9 @@ class Engine:
         self._fwd_plans, self._bwd_plan, self._plan_epoch = {}, None, 0
         self._logits = self._gout = self._flat = None
         self._pack_on_side = False
-        self.overlap_pack = os.environ.get("MCAMD_OVERLAP_PACK", "auto")
         self.fold_dead = os.environ.get("MCAMD_FOLD_DEAD", "1") == "1"
-        self.bn_narrow_on = os.environ.get("MCAMD_BN_NARROW", "1") == "1"
-        self.bwd_from_act = os.environ.get("MCAMD_BWD_FROM_ACT", "1") == "1"
+        self.bn_narrow_on = True      # BatchNorm / activation passes of a folded producer on its kept channels only
+        self.bwd_from_act = True      # split-operand engines: BatchNorm backward of PLAIN blocks from the stored activation
         self._side_stream = None
         self._side_concurrent = True
         self._side_ws = None
@@ -246,8 +243,8 @@ class Engine:
         # its MFMA work, conv19's launch -19 %); every other kernel only sees a different row pitch.  Training engines only
         # (inference engines keep the padded form); since round 4 also the split-operand ones, whose backward pass is the same.
         self.shared_halo_maxw = 0
-        if self.train_layout and os.environ.get("MCAMD_SHARED_HALO", "1") == "1":
-            self.shared_halo_maxw = int(os.environ.get("MCAMD_SHARED_HALO_MAXW", "26"))
+        if self.train_layout:
+            self.shared_halo_maxw = 26
 
         def pad_for(w):
             return 1 if (w <= self.shared_halo_maxw and w >= 4) else 0
@@ -265,7 +262,7 @@ class Engine:
         if self.precise:
             chans = [shape[t][0] for ci in conv_inds for t in fused[ci][1:] if t is not None and consumers.get(t)]
             chans += [shape[srcs[i][0]][0] + shape[srcs[i][1]][0] for i, (t, _) in enumerate(bops) if t == "route" and len(srcs[i]) == 2]
-            planes = 2 if (all(c % 32 == 0 for c in chans) and os.environ.get("MCAMD_TWO_PLANES", "1") == "1") else 3
+            planes = 2 if all(c % 32 == 0 for c in chans) else 3
         self.act_planes = planes
 
         for ind, (t, _) in enumerate(bops):
@@ -287,7 +284,7 @@ class Engine:
         c0 = conv_inds[0]
         stem_block_ok = (cin0 == 3 and first_k == 3 and int(blocks[c0 + 1]["filters"]) == 32
                          and int(blocks[c0 + 1]["batch_normalize"]) and fused[c0][0] == L.DST_POOL and fused[c0][2] is None
-                         and W0 % 32 == 0 and H0 % 2 == 0 and os.environ.get("MCAMD_STEM_FUSED", "1") == "1")
+                         and W0 % 32 == 0 and H0 % 2 == 0)
         # (not in training: there the first block's operand rounding alone costs 1.9e-2 on the logits, MIXED_BUDGET_TRAIN)
         self.stem = (cin0 == 3 and first_k == 3) and (not self.precise or (self.precision == "mixed" and stem_block_ok
                                                                           and not self.for_training))
@@ -296,8 +293,7 @@ class Engine:
         # recomputes the block from the NHWC4 image, so the block's fp32 raw output (1.4 GB at B=64) is read once by the
         # activation pass and never again, and its 0.7 GB dY never exists.  The fused forward runs too, into a scratch
         # output, only to fill the workspace its backward reads (Gram sums) and its own self-consistent coefficients.
-        self.stem_shadow = bool(self.precise and self.for_training and not self.stem and stem_block_ok
-                                and os.environ.get("MCAMD_STEM_SHADOW", "1") == "1")
+        self.stem_shadow = bool(self.precise and self.for_training and not self.stem and stem_block_ok)
         ld0 = 4 if self.stem else ops.round_up(cin0 * (3 if self.precise else 1), 32)
         place[-1] = _T(new_buf(B, H0, W0, ld0), ld0, 0, cin0, H0, W0, cin0 if (self.precise and not self.stem) else 0)
         materialized = set()
@@ -432,20 +428,18 @@ class Engine:
             # the first block as one unit (conv1 + BN + LeakyReLU + maxpool, csrc/conv_stem_block.hip): neither its raw
             # output (709 MB at B=64) nor the gradient wrt it is ever stored
             lay.fused_stem = bool(lay.stem and lay.bn is not None and lay.mode == L.DST_POOL and lay.out2_id is None
-                                  and lay.cout == 32 and lay.W % 32 == 0 and lay.H % 2 == 0 and lay.border is None
-                                  and os.environ.get("MCAMD_STEM_FUSED", "1") == "1")
+                                  and lay.cout == 32 and lay.W % 32 == 0 and lay.H % 2 == 0 and lay.border is None)
             # physically slim models keep 8 / 16 / 24 filters here: the inference-mode forward takes the same kernel
             lay.fused_stem_eval = bool(lay.stem and lay.bn is not None and lay.mode == L.DST_POOL and lay.out2_id is None
-                                       and lay.cout in (8, 16, 24) and lay.W % 32 == 0 and lay.H % 2 == 0 and lay.border is None
-                                       and os.environ.get("MCAMD_STEM_FUSED", "1") == "1")
+                                       and lay.cout in (8, 16, 24) and lay.W % 32 == 0 and lay.H % 2 == 0 and lay.border is None)
             lay.stem_shadow = bool(li_is_first(lay) and self.stem_shadow and lay.bn is not None and lay.mode == L.DST_POOL
                                    and lay.out2_id is None and lay.cout == 32 and lay.border is None)
             # ... and (round 4) its FORWARD pass is the fused first block too, on SPLIT operands: a statistics pass over the
             # hi / lo NHWC4 images that writes nothing but per-channel sums, then conv + BatchNorm + LeakyReLU + MaxPool
             # recomputed and written once as the pooled hi | lo planes (csrc/conv_stem_block.hip, SPLIT).  Replaces the fp32
             # first convolution's 1.4 GB raw output, its BatchNorm pass and the scratch forward of the plain block:
-            # 1.16 -> ~0.3 ms per B=64 step.  MCAMD_STEM_SPLIT=0: the round-3 path.
-            lay.stem_split = bool(lay.stem_shadow and os.environ.get("MCAMD_STEM_SPLIT", "1") == "1")
+            # 1.16 -> 0.41 ms per B=64 step (13.85 -> 12.98 ms, A/B on one box).
+            lay.stem_split = bool(lay.stem_shadow)
             if lay.stem_shadow:
                 lay.sh_img = ops.alloc_padded(B, lay.H, lay.W, 4, dev)                    # NHWC4 fp16 image
                 lay.sh_geom = ops.geom(B, lay.H, lay.W, 3, 3, lay.cout, 4, 0, 1)
@@ -474,8 +468,7 @@ class Engine:
                     # (csrc/conv_stem_f32.hip) instead of hi | lo | hi image planes through the generic MFMA kernel
                     # (layout 0.38 + conv 0.86 ms per B=64 step -> 0.4 ms, and exact fp32 products).
                     lay.stem_f32 = bool(self.precise and li_is_first(lay) and lay.cin == 3 and lay.k == 3 and lay.cout == 32
-                                        and lay.bn is not None and not lay.stem_split
-                                        and os.environ.get("MCAMD_STEM_F32", "1") == "1")
+                                        and lay.bn is not None and not lay.stem_split)
                     # zero-initialised: with filter compaction the convolution writes the kept channels only
                     # (the split-operand fused first block never stores its raw output)
                     lay.y = None if lay.stem_split else torch.zeros(lay.M * lay.cout, dtype=torch.float32 if self.precise else ops.HALF,
@@ -498,7 +491,7 @@ class Engine:
         self._pack_key, self._pack_table, self._pack_keep = None, None, []
         self.compact = os.environ.get("MCAMD_COMPACT", "1") == "1" and not self.precise
         self.fuse_eval = os.environ.get("MCAMD_FUSE_EVAL", "1") == "1"
-        self.compact_gran = int(os.environ.get("MCAMD_COMPACT_GRAN", "0"))
+        self.compact_gran = 0         # granularity of a compacted filter count: 0 = 64, or 8 below 128 filters
         maxc = max(l.cout for l in self.layers)
         self.bwd_ws = torch.empty(ops.bn_act_bwd_workspace_bytes(maxc), dtype=torch.uint8, device=dev)
         self.params = list(model.parameters())
@@ -643,12 +636,11 @@ class Engine:
         # (filter masks) their fold + re-pack runs on the second stream under the first block's Gram / forward kernels and
         # forward() makes the launch stream wait for it in front of the second block (self._pack_event): 7.17 -> 7.10 ms
         # per filter-pruned step.  Dense: the lone re-pack launch gains nothing from it (9.69 vs 9.73 ms), so it stays on
-        # the launch stream (MCAMD_OVERLAP_PACK=1 forces the overlap, 0 forbids it).
+        # the launch stream.
         self._pack_on_side = False
         side = None
-        want = self.overlap_pack
         if (training and self.overlap_wgrad and self.events is None and self.layers[0].fused_stem
-                and (want == "1" or (want == "auto" and any(lay.fold is not None for lay in self.layers)))):
+                and any(lay.fold is not None for lay in self.layers)):
             main = torch.cuda.current_stream(self.device)
             side = self._get_side_stream()
             side.wait_stream(main)            # the optimizer step that produced these weights
@@ -867,8 +859,8 @@ class Engine:
     # ------------------------------------------------------------------ launch plans
     def _ptr_sig(self):
         """Everything a recorded plan holds BY VALUE that torch may change under it: addresses of parameters, masks and
-        BatchNorm buffers, of the engine's own persistent flat-gradient / logit-gradient buffers (MCAMD_DBG_FRESH_FLAT
-        re-allocates them), and the BatchNorm momentum / eps the coefficient kernels were recorded with."""
+        BatchNorm buffers, of the engine's own persistent flat-gradient / logit-gradient buffers, and the BatchNorm momentum /
+        eps the coefficient kernels were recorded with."""
         sig = [p.data_ptr() for p in self.params]
         sig.append(self._flat.data_ptr() if self._flat is not None else 0)
         sig.append(self._gout.data_ptr() if self._gout is not None else 0)
@@ -1076,7 +1068,7 @@ class Engine:
         # 1 / grad_scale factor their finish passes apply anyway), so the summed all-reduce result is the average and no
         # separate 202 MB division pass follows it (dp.attach sets model._grad_div)
         D = S * float(getattr(self.model, "_grad_div", 1.0))
-        if self._flat is None or os.environ.get("MCAMD_DBG_FRESH_FLAT") == "1":
+        if self._flat is None:
             # every element is written by the kernels (wgrad finish / dgamma / dbeta / dbias): no memset needed
             self._flat = torch.empty(self.total_params, dtype=torch.float32, device=self.device)
             self._gout = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
@@ -1159,7 +1151,7 @@ class Engine:
     def _backward_body(self, gmap, main, side, S, D, ready):
         """The layer walk of the backward pass: library calls only (recordable); `ready(lay)` after the last launch that
         writes block `lay`'s slice of the flat gradient."""
-        # Weight gradients go to the second stream in groups of `chunk` blocks (MCAMD_WGRAD_CHUNK, default 1 = each block
+        # Weight gradients go to the second stream in groups of `chunk` blocks (self.wgrad_chunk, 1 = each block
         # at once).  Every hand-over is an event record in the launch stream's queue plus a cross-queue wait; grouping 2-3
         # blocks per hand-over measured the same (9.63 / 9.64 / 9.64 ms per dense step), 4 and 6 slower (9.71 / 9.75: the
         # late start costs more overlap than the saved events).  dY and the block inputs stay in place until the next

@@ -71,11 +71,5 @@ em = ((mean.double() - mref).abs() / mref.abs().clamp_min(1e-3)).max().item()
 ei = ((invstd.double() - iref).abs() / iref).max().item()
 print("batch statistics from the Gram matrix: max rel err mean %.2e invstd %.2e   (E[y^2]/var up to %.1f)" % (
     em, ei, float((s2 / M / vref).max())))
-for gw in ("256", "512"):
-    os.environ["MCAMD_STEM_GRAM_WGS"] = gw
-    print("B=%d fwd, Gram grid %s: %.1f us" % (B, gw, timeit(fwd)))
-os.environ["MCAMD_STEM_GRAM_WGS"] = "256"
-for un in ("1", "2", "4"):
-    os.environ["MCAMD_STEM_FWD_UN"] = un
-    print("B=%d fwd (gram + sums + coeffs + fused pass) UN=%s: %.1f us" % (B, un, timeit(fwd)))
+print("B=%d fwd (gram + sums + coeffs + fused pass): %.1f us" % (B, timeit(fwd)))
 print("B=%d bwd (fused pass + sums + finish): %.1f us" % (B, timeit(bwd)))
