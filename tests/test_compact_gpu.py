@@ -178,12 +178,19 @@ def test_compaction_yolov2_40pct(dev):
     head = rel_l2(g_c["models.30.conv23.weight"], g_d["models.30.conv23.weight"])
     print("parameter gradients compact vs dense engine: head %.2e, median %.2e, worst %s" % (
         head, median, ", ".join("%s %.2e" % kv for kv in ranked[:4])))
+    tail = {n: errs[n] for n in list(g_c)[-6:] if n in errs}      # conv22 / bn22 / conv23: the blocks behind the last amplification
+    print("last blocks: " + ", ".join("%s %.1e" % (n.replace("models.", ""), v) for n, v in tail.items()))
     # This end-to-end comparison is chaotic by nature (which realisation of the fp16 noise the first layers'
-    # BatchNorm vectors see changes with any re-grouping of fp32 partial sums), so it only checks the head and the
-    # bulk; the TIGHT check of the compacted launches at these shapes -- every kernel of every block against fp32
-    # `F.conv2d(x, w * mask)` on identical inputs at 1e-3 / 2e-3 -- is
-    # tests/test_model_gpu.py::test_layerwise_teacher_forced_yolov2_filter40 (+ ..._filter60_b64_tail).
-    assert head < 3e-2 and median < 0.25
+    # BatchNorm vectors see changes with any re-grouping of fp32 partial sums): a 1.6e-2 difference of the train-mode logits
+    # flips LeakyReLU derivative signs on ~sqrt(eps) of the elements, and EVERY parameter gradient of the first 21 blocks then
+    # differs by 0.1-0.6 between the two engines (measured, round 4: median 0.20, worst bn2.weight 0.56) -- there is no quiet
+    # subset up there.  The bounds: the head and the last blocks (where nothing amplifies any more), the bulk, and a bounded
+    # worst case; the TIGHT checks of the compacted launches at these shapes -- every kernel of every block against fp32
+    # `F.conv2d(x, w * mask)` on identical inputs at 1e-3 / 2e-3, and folded against unfolded backward launches on identical
+    # inputs at 1e-3 -- are tests/test_model_gpu.py::test_layerwise_teacher_forced_yolov2_filter40 (+ ..._filter40_b64_head,
+    # ..._filter60_b64_tail) and test_fold_dead_ab_on_identical_inputs_yolov2_filter40 above.
+    assert head < 3e-2 and median < 0.25 and worst < 0.8
+    assert max(tail.values()) < 0.15, tail
     for (name, p), mk in zip([(n, p) for n, p in m.named_parameters() if p.dim() == 4], masks):
         assert bool((g_c[name][mk.cpu() == 0] == 0).all()), name
     # eval mode uses the same plan (in the plain-fp16 mode; the split-operand eval default does not compact)
@@ -198,6 +205,91 @@ def test_compaction_yolov2_40pct(dev):
         b = m(x).cpu()
         os.environ.pop("MCAMD_COMPACT")
     assert rel_l2(a, b) < 5e-3
+
+
+def test_fold_dead_ab_on_identical_inputs_yolov2_filter40(dev):
+    """MCAMD_FOLD_DEAD=1 against MCAMD_FOLD_DEAD=0 at the filter40 shapes, TEACHER-FORCED (ADVICE r02 item 3 / VERDICT r03
+    item 6): the two engines round at different points in the forward pass (exact folded constants against stored fp16
+    ones), so end to end they diverge chaotically; here every folding consumer's backward launches are re-issued on both
+    engines with the SAME dY and the SAME kept input channels.  The folded weight gradient (augmented problem + unfold)
+    must equal the unfolded one on every column -- kept inputs, dead inputs, removed filters' zero rows -- within 1e-3,
+    and the dead channels' dbeta that the fold delivers (mcamd_unfold_wgrad) must equal what the unfolded engine's own
+    input gradient gives the producer's BatchNorm backward, leaky'(beta_c) * sum_pixels G[:, c], within 2e-3."""
+    from modelcompression_amd import ops
+    blocks, m, masks = _model(YOLOV2_VOC_CFG, dev, 12, 40.0)
+    m.grad_scale = 16.0                                    # (conv2 keeps one live filter on this seed: see test_model_gpu.py)
+    g = torch.Generator().manual_seed(23)
+    Bn = 8
+    x, gout = torch.rand(Bn, 3, 416, 416, generator=g).to(dev), torch.randn(Bn, 125, 13, 13, generator=g).to(dev)
+    engs = {}
+    for fold in ("1", "0"):
+        os.environ["MCAMD_FOLD_DEAD"] = fold
+        try:
+            m._engines = {}
+            m.train()
+            out = m(x)
+            m.zero_grad()
+            out.backward(gout)
+            engs[fold] = list(m._engines.values())[0]
+        finally:
+            os.environ.pop("MCAMD_FOLD_DEAD", None)
+    A, Bq = engs["1"], engs["0"]
+    folded = [lay for lay in A.layers if lay.fold is not None]
+    assert len(folded) >= 8 and all(lay.fold is None for lay in Bq.layers)
+    S = D = A.grad_scale
+    checked = 0
+    for ca in folded:
+        cb = Bq.layers[ca.li]
+        prod = ca.fold
+        assert cb.n_act == ca.n_act and (cb.perm is None) == (ca.perm is None) and cb.in_perm is not None
+        assert torch.equal(cb.in_perm, ca.in_perm)
+        nk = ca.fold_cin
+        # identical inputs: A's dY, and A's kept input channels in B's buffer (B keeps its own stored constants behind them)
+        cb.dy.copy_(ca.dy)
+        ta, tb = ca.tin, cb.tin
+        va = ops.padded_view(A.bufs[ta.buf], Bn, ta.H, ta.W, ta.ld)
+        vb = ops.padded_view(Bq.bufs[tb.buf], Bn, tb.H, tb.W, tb.ld)
+        vb[:, 1:-1, 1:-1, tb.choff:tb.choff + nk] = va[:, 1:-1, 1:-1, ta.choff:ta.choff + nk]
+        w, mask = ca.conv.weight.data, (ca.conv.mask if ca.conv.mask_flag else None)
+        ws = torch.empty(max(ops.wgrad_workspace_bytes(ca.geom_act), ops.wgrad_workspace_bytes(cb.geom_act)), dtype=torch.uint8, device=dev)
+        # A: augmented problem (kept inputs + the ones-channel), then back to OIHW and to the producer's dbeta
+        dwaug = torch.zeros_like(ca.dwaug)
+        gw_a = torch.zeros_like(w)
+        db_a, dg_a = torch.zeros_like(prod.bn.bias.data), torch.zeros_like(prod.bn.bias.data)
+        ops.conv_wgrad(ca.geom_act, A.bufs[ta.buf], ca.dy, ca.cout_p, 0, dwaug, None, D, None, ws)
+        ops.unfold_wgrad(w, mask, ca.g_rows, ca.g_cols, prod.bn.bias.data, prod.slope, ca.n_act, nk, dwaug, gw_a, db_a, dg_a,
+                         accumulate=False)
+        # B: the unfolded problem on all input channels (row / column maps of the compaction)
+        gw_b = torch.zeros_like(w)
+        ops.conv_wgrad(cb.geom_act, Bq.bufs[tb.buf], cb.dy, cb.cout_p, 0, gw_b, mask, D, None, ws, rows=cb.g_rows, cols=cb.g_cols)
+        e_w = rel_l2(gw_a.cpu(), gw_b.cpu())
+        dead = ca.in_perm[nk:].cpu()                      # module indices of the producer's dead channels
+        da, db_ = gw_a.cpu()[:, dead].double(), gw_b.cpu()[:, dead].double()
+        share = float(db_.norm() / gw_b.double().norm())   # how much of the gradient sits in the dead columns
+        # A dead input is a constant, so its column is v_c * sum_{p: p + tap inside} dY[p][n]: for a 1x1 consumer that is the
+        # plain pixel sum of a BatchNorm-backward output, ZERO up to the fp16 rounding noise of dY (conv4: 1e-5 of the
+        # gradient's norm) -- compared on the gradient's scale there, relatively where the columns carry weight (3x3: borders)
+        e_dead = float((da - db_).norm() / db_.norm()) if share > 1e-3 else float((da - db_).norm() / gw_b.double().norm())
+        # dbeta of the dead channels from B's own input gradient: the channel is the constant leaky(beta_c), its
+        # pre-activation beta_c, so sum_pixels g_z = leaky'(beta_c) * sum_pixels G[:, c]
+        # (the same dgrad launch with the fp32 NCHW epilogue: the stored fp16 G saturates on this seed's conv2 -- one live
+        # filter carries the whole gradient of the 208x208 map -- and the comparison is about the fold, not about that)
+        gin = torch.zeros(Bn, cb.cin, cb.H, cb.W, device=dev)
+        ops.conv_dgrad_nchw(cb.geom_act, cb.dy, cb.cout_p, 0, cb.wd, gin)
+        G = gin[:, nk:ca.in_perm.numel()].double().sum((0, 2, 3)).float().cpu() / S
+        beta = prod.bn.bias.detach().cpu()[dead]
+        expect = torch.where(beta > 0, torch.ones_like(beta), torch.full_like(beta, prod.slope)) * G
+        # (a 1x1 consumer's share of dbeta is W . sum_p dY[p] again -- noise around zero: on the scale of the producer's whole
+        # dbeta vector there, relatively for the 3x3 consumers, whose border taps make it a real number)
+        e_b = rel_l2(db_a.cpu()[dead], expect) if ca.k == 3 else float(
+            (db_a.cpu()[dead].double() - expect.double()).norm() / prod.bn.bias.grad.double().norm().cpu())
+        print("conv%-2d (producer conv%d, %d kept + %d dead inputs): dW %.1e (dead columns %.1e, %.1e of the norm), dbeta of the dead "
+              "channels %.1e" % (ca.li + 1, prod.li + 1, nk, dead.numel(), e_w, e_dead, share, e_b))
+        assert e_w < 1e-3 and e_dead < 1e-3, (ca.li, e_w, e_dead)
+        assert e_b < 2e-3, (ca.li, e_b)
+        assert float(dg_a.abs().max()) == 0.0            # xhat = 0 for a dead filter: no dgamma
+        checked += 1
+    assert checked >= 8
 
 
 @pytest.mark.parametrize("cfg,shape", [(MINI, (4, 3, 64, 96)), (YOLOV2_VOC_CFG, (4, 3, 416, 416))], ids=["mini", "yolov2"])
