@@ -47,13 +47,30 @@ top = sorted(out.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches"])[:
 json.dump(dict(top), open("profiles/%s_pmc_per_kernel.json" % tag, "w"), indent=1)
 dom = [k for k in out if k.startswith("void igemm_kernel<") or k.startswith("void igemm_pp_kernel<")]
 if dom:
+    import subprocess
+    try:
+        build = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:
+        build = "?"
     k = max(dom, key=lambda k: out[k]["launches"] * out[k]["avg_us"])
     json.dump({"kernel": k, "hbm_bytes_per_launch": out[k]["hbm_bytes_per_launch"], "launches_profiled": out[k]["launches"],
                "fetch_bytes_per_launch": out[k]["fetch_bytes_per_launch"], "write_bytes_per_launch": out[k]["write_bytes_per_launch"],
-               "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"},
+               "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)",
+               # bench.py copies this string into roofline.traffic_source: the number in a bench line is READ from this
+               # file, it was not measured by that run
+               "source": "profiles/%s_pmc_per_kernel.json (tools/collect_profiles.sh at commit %s; NOT measured by the bench run "
+                         "that prints it)" % (tag, build)},
               open("profiles/dominant_kernel_traffic.json", "w"), indent=1)
     print(k, out[k])
 shutil.copy(os.path.join(src, "bench.json"), "profiles/%s_bench.json" % tag)
+for extra in ("region", "filter40", "weight80_b32_region", "slim60"):
+    f = os.path.join(src, "bench_%s.json" % extra)
+    if os.path.exists(f) and os.path.getsize(f) > 0:
+        shutil.copy(f, "profiles/%s_bench_%s.json" % (tag, extra))
+st16 = one("stats_fp16/*/*kernel_stats.csv")
+if st16:
+    shutil.copy(st16, "profiles/%s_kernel_stats_fp16.csv" % tag)
+    shutil.copy(os.path.join(src, "layer_table_fp16.txt"), "profiles/%s_layer_table_fp16.txt" % tag)
 
 # pruning workload: kernel stats + HBM bytes read per launch of the magnitude-select scan
 pst = one("prune_stats/*/*kernel_stats.csv")
