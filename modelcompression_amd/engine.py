@@ -35,10 +35,11 @@ class _T:
     """Where a block output lives: channel slice [choff, choff+C) of a padded NHWC buffer.  `ps`: plane stride of
     the buffer when it holds split (hi | lo | hi) activations (precision "fp16x3"): the slice repeats at
     choff + ps and choff + 2 * ps."""
-    __slots__ = ("buf", "ld", "choff", "C", "H", "W", "ps")
+    __slots__ = ("buf", "ld", "choff", "C", "H", "W", "ps", "ps0")
 
     def __init__(self, buf, ld, choff, C, H, W, ps=0):
         self.buf, self.ld, self.choff, self.C, self.H, self.W, self.ps = buf, ld, choff, C, H, W, ps
+        self.ps0 = ps          # (a folded producer's planes move closer together: Engine._plan_folds)
 
 
 class _Layer:
@@ -489,7 +490,8 @@ class Engine:
         self.wgrad_ws = torch.empty(max(wbytes, 16), dtype=torch.uint8, device=dev)
         self._mask_keys = None
         self._pack_key, self._pack_table, self._pack_keep = None, None, []
-        self.compact = os.environ.get("MCAMD_COMPACT", "1") == "1" and not self.precise
+        # filter compaction + dead-input folding; since round 4 also in the split-operand engines (two-plane storage)
+        self.compact = os.environ.get("MCAMD_COMPACT", "1") == "1" and (not self.precise or self.act_planes == 2)
         self.fuse_eval = os.environ.get("MCAMD_FUSE_EVAL", "1") == "1"
         self.compact_gran = 0         # granularity of a compacted filter count: 0 = 64, or 8 below 128 filters
         maxc = max(l.cout for l in self.layers)
@@ -601,12 +603,10 @@ class Engine:
                 lay.wp.zero_()
                 if lay.wd is not None:
                     lay.wd.zero_()
-        if self.precise:
-            self._pack_split(training)
-            self._packed_sig = sig
-            self.model._weights_dirty = False
-            return
-        # geom_act / g_rows / g_cols: physical channel order (kept filters first, permuted inputs); identity = None
+        # geom_act / g_rows / g_cols: physical channel order (kept filters first, permuted inputs); identity = None.
+        # Split-operand engines: forward = fp16 of [w_hi | w_hi | w_lo] along the input channels (w_hi = fp16(w * mask),
+        # w_lo = fp16(w * mask - w_hi)), matching the [x_hi | x_lo | x_hi] activation planes, written by the one-launch
+        # packer itself (mcamd_pack_job.split); dgrad = the plain fp16 packing (the backward pass multiplies plain operands)
         tkey = tuple((s_[0], None if s_[2] is None else s_[2][0]) for s_ in sig)
         if tkey != self._pack_key:          # weight / mask storage moved, or the compaction changed: new job table
             jobs, self._pack_keep = [], []
@@ -622,16 +622,20 @@ class Engine:
                 self._pack_keep += [w, mask]
                 if lay.fold is not None:     # augmented weights (kept inputs + the folded ones-channel), rebuilt per step
                     jobs.append(dict(w=lay.waug, mask=None, rows=None, cols=None, cout=lay.n_act, cin=lay.fold_aug,
-                                     ksize=lay.k, dst_fwd=lay.wp, dst_dgrad=lay.wd))
+                                     ksize=lay.k, dst_fwd=lay.wp, dst_dgrad=lay.wd, split=lay.level == 3))
                     continue
                 jobs.append(dict(w=w, mask=mask, rows=lay.g_rows, cols=lay.g_cols, cout=lay.n_act, cin=lay.cin, ksize=lay.k,
-                                 dst_fwd=lay.wp, dst_dgrad=lay.wd))
+                                 dst_fwd=lay.wp, dst_dgrad=lay.wd, split=lay.level == 3))
             self._pack_table = ops.pack_table(jobs, self.device) if jobs else None
             self._pack_key = tkey
         for lay in self.layers:
+            mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
             if lay.stem:
-                mask = lay.conv.mask.contiguous() if lay.conv.mask_flag else None
                 ops.pack_weights(lay.geom_act, lay.conv.weight.data, mask, True, False, lay.wp, None, rows=lay.g_rows)
+            if getattr(lay, "stem_split", False):          # hi and lo stem packings of the split-operand fused first block
+                ops.pack_stem_split(lay.conv.weight.data, mask, lay.sh_wp, lay.sh_wp_lo)
+            elif getattr(lay, "stem_shadow", False):
+                ops.pack_weights(lay.sh_geom, lay.conv.weight.data, mask, True, False, lay.sh_wp, None)
         # The layers behind the first block are not needed until that block's forward is done: with folded layers
         # (filter masks) their fold + re-pack runs on the second stream under the first block's Gram / forward kernels and
         # forward() makes the launch stream wait for it in front of the second block (self._pack_event): 7.17 -> 7.10 ms
@@ -670,44 +674,21 @@ class Engine:
         self._packed_sig = sig
         self.model._weights_dirty = False
 
-    def _pack_split(self, training=False):
-        """Packings of the split-operand modes: forward = fp16 of [w_hi | w_hi | w_lo] along the input channels
-        (w_hi = fp16(w * mask), w_lo = fp16(w * mask - w_hi)), matching the [x_hi | x_lo | x_hi] activation planes;
-        dgrad = the plain fp16 packing (the backward pass multiplies plain operands).  One launch for all layers: the
-        packer splits the master itself (mcamd_pack_job.split; round 3 formed the three parts with torch ops per layer,
-        ~1.2 ms of small kernels per step)."""
-        key = tuple((lay.conv.weight.data_ptr(), lay.conv.mask.data_ptr() if lay.conv.mask_flag else 0) for lay in self.layers)
-        if key != self._pack_key:
-            jobs, self._pack_keep = [], []
-            for lay in self.layers:
-                w = lay.conv.weight.data
-                if w.dtype != torch.float32 or not w.is_contiguous():
-                    raise McamdError("conv weights must be contiguous fp32 (master copy)")
-                mask = lay.conv.mask if lay.conv.mask_flag else None
-                if mask is not None and not mask.is_contiguous():
-                    raise McamdError("conv masks must be contiguous")
-                if lay.stem:
-                    continue
-                self._pack_keep += [w, mask]
-                jobs.append(dict(w=w, mask=mask, rows=None, cols=None, cout=lay.cout, cin=lay.cin, ksize=lay.k,
-                                 dst_fwd=lay.wp, dst_dgrad=lay.wd, split=lay.level == 3))
-            self._pack_table = ops.pack_table(jobs, self.device) if jobs else None
-            self._pack_key = key
-        # (on the second stream under the fused split-operand first block, together with that block's Gram pass: measured
-        # 12.951 vs 12.974 ms per step, i.e. nothing -- the first block's own passes are HBM-bound too; not kept)
-        self._pack_on_side = False
-        if self._pack_table is not None:
-            ops.pack_many(*self._pack_table)
-        for lay in self.layers:
-            mask = lay.conv.mask if lay.conv.mask_flag else None
-            if lay.stem:
-                ops.pack_weights(lay.geom_f, lay.conv.weight.data, mask, True, False, lay.wp, None)
-            if getattr(lay, "stem_split", False):
-                ops.pack_stem_split(lay.conv.weight.data, mask, lay.sh_wp, lay.sh_wp_lo)
-            elif getattr(lay, "stem_shadow", False):
-                ops.pack_weights(lay.sh_geom, lay.conv.weight.data, mask, True, False, lay.sh_wp, None)
-
     # ------------------------------------------------------------------ filter compaction
+    def _set_geom_f(self, lay):
+        """Forward geometry of a layer in a split-operand engine, over the filters it computes and the input channels it
+        reads (all of them, or kept + ones of a folded producer): the K-concatenated problem [x_hi | x_lo | x_hi] x
+        [w_hi | w_hi | w_lo] on the two planes `tin.ps` apart (x_wrap), or the plain geometry for a block left on plain
+        operands (it reads the hi plane, like every backward launch)."""
+        if not self.precise:
+            return
+        cin_eff = lay.fold_aug if lay.fold is not None else lay.cin
+        if lay.level == 1:
+            lay.geom_f = lay.geom_act
+            return
+        wrap = 2 * lay.tin.ps if (self.act_planes == 2 and lay.li > 0) else 0      # (the network input keeps three planes)
+        lay.geom_f = ops.geom(self.B, lay.H, lay.W, lay.k, lay.level * cin_eff, lay.n_act, lay.tin.ld, 0, 0, lay.pad, wrap)
+
     def _update_compaction(self):
         """Sparse-masked path: skip the filters a filter mask removed (north_star: "a sparse-masked wgrad
         path that skips zeroed filters"; the reference multiplies by the mask and computes them anyway,
@@ -742,7 +723,8 @@ class Engine:
                     # (the 3-channel first layer keeps all its filters: its streaming kernels -- stem_fwd / wgrad_stem --
                     # exist for 32 and 64 filters only, and a ragged count falls back to the generic kernels:
                     # measured 0.22 -> 0.33 ms forward, 0.19 -> 0.32 ms weight gradient at 40 % pruning)
-                    if self.compact and lay.bn is not None and not lay.stem:
+                    # (... nor does the first block of a split-operand engine: its fused / fp32 kernels want all 32 filters)
+                    if self.compact and lay.bn is not None and not lay.stem and not (self.precise and lay.li == 0):
                         # kept count rounded up so the kernels keep their tile shapes: whole 64-filter tiles
                         # (the 9-tap wgrad and the 128-wide igemm tiles) where the layer has them
                         gran = self.compact_gran or (64 if lay.cout >= 128 else 8)
@@ -759,8 +741,9 @@ class Engine:
                 lay.gather = perm is not None or in_perm is not None
                 lay.g_rows = perm[:n_act].to(torch.int32).contiguous() if perm is not None else None
                 lay.g_cols = in_perm.to(torch.int32).contiguous() if in_perm is not None else None
-                if lay.bn is not None and not self.precise and not lay.fused_stem:
-                    rows = ops.stats_rows(lay.geom_act)
+                self._set_geom_f(lay)
+                if lay.bn is not None and not lay.fused_stem and lay.y is not None and not lay.stem_f32:
+                    rows = ops.stats_rows(lay.geom_f, L.EPI_RAW_F32) if self.precise else ops.stats_rows(lay.geom_act)
                     if lay.stats.shape[0] != rows:
                         lay.stats = torch.zeros(rows, 2, lay.stats.shape[2], dtype=torch.float32, device=dev)
                     else:
@@ -804,7 +787,14 @@ class Engine:
             self._fold_key = None
             if lay.gin is not None:
                 lay.gin.zero_()       # a folding consumer's dgrad leaves the dead channels of G untouched: they must be finite
+            for t in (lay.tin, getattr(lay, "out_t", None), getattr(lay, "out2_t", None)):
+                if t is not None and t.ps != t.ps0:      # planes of a formerly folded producer: back to the full width
+                    t.ps = t.ps0
+                    v = ops.padded_view(self.bufs[t.buf], self.B, t.H, t.W, t.ld)[:, 1:-1, 1:-1]
+                    v[..., t.choff:t.choff + 2 * t.C] = 0
         if not (self.compact and self.fold_dead):
+            for lay in self.layers:
+                self._set_geom_f(lay)
             return 16
         wbytes = 16
         for prod in self.layers:
@@ -817,20 +807,31 @@ class Engine:
             # the augmented channel count keeps the kernels' fast shapes (whole 64-channel K blocks for wide inputs), and
             # folding must remove at least a quarter of the input channels to pay for its ragged tiles (measured on
             # conv19 of the 40 % model, 840 of 1024 channels: dgrad 0.188 -> 0.294 ms)
-            aug = ops.round_up(prod.n_act + 1, 64 if prod.cout >= 256 else 8)
+            aug = ops.round_up(prod.n_act + 1, 64 if prod.cout >= 256 else (32 if self.precise else 8))
             if aug > 0.75 * prod.cout:
                 continue
-            prod.ones_idx, prod.skip_dead = prod.n_act, True
-            prod.fold_consumers = sorted(cons, key=lambda c: -c.li)      # backward order: the first one initialises dbeta
             # BatchNorm / activation passes on the kept channels only (their kernels keep one 8-channel group per thread:
             # 8 x a power of two channels); the ones-channel is then written once, here, instead of by every forward pass
             ch = prod.n_act // 8
-            prod.bn_narrow = prod.n_act % 8 == 0 and ch >= 1 and (ch & (ch - 1)) == 0 and ch <= 256 and self.bn_narrow_on
+            narrow = prod.n_act % 8 == 0 and ch >= 1 and (ch & (ch - 1)) == 0 and ch <= 256 and self.bn_narrow_on
+            if self.precise and not narrow:
+                # Split-operand engines store a tensor as hi | lo planes; a folding consumer's K-concatenated geometry wants
+                # them `aug` channels apart (x_wrap = 2 aug), so the producer's activation pass must write `aug`-spaced planes
+                # -- which only works when it writes the kept channels alone (a full-width pass would overlap its own lo
+                # plane).  Producers whose kept count is not 8 x a power of two stay compacted but unfolded here.
+                continue
+            prod.ones_idx, prod.skip_dead = prod.n_act, True
+            prod.fold_consumers = sorted(cons, key=lambda c: -c.li)      # backward order: the first one initialises dbeta
+            prod.bn_narrow = narrow
             if prod.bn_narrow:
                 for t in (prod.out_t, prod.out2_t):
                     if t is not None:
                         v = ops.padded_view(self.bufs[t.buf], self.B, t.H, t.W, t.ld)[:, 1:-1, 1:-1]
-                        v[..., t.choff + prod.n_act + 1:t.choff + prod.cout] = 0
+                        if self.precise:                 # both planes: aug apart from now on, zero but for the ones-channel
+                            t.ps = aug
+                            v[..., t.choff:t.choff + 2 * t.C] = 0
+                        else:
+                            v[..., t.choff + prod.n_act + 1:t.choff + prod.cout] = 0
                         v[..., t.choff + prod.n_act] = 1
                 prod.dy.zero_()
             for c in cons:
@@ -841,11 +842,13 @@ class Engine:
                 c.gather = True
                 c.waug = torch.zeros(c.n_act, c.fold_aug, c.k, c.k, dtype=torch.float32, device=dev)
                 c.dwaug = torch.zeros_like(c.waug)
-                if c.bn is not None:
-                    rows = ops.stats_rows(c.geom_act)
-                    if c.stats.shape[0] != rows:
-                        c.stats = torch.zeros(rows, 2, c.stats.shape[2], dtype=torch.float32, device=dev)
                 wbytes = max(wbytes, ops.wgrad_workspace_bytes(c.geom_act))
+        for lay in self.layers:          # (plane strides may have moved under any layer: every forward geometry again)
+            self._set_geom_f(lay)
+            if lay.bn is not None and not lay.fused_stem and lay.y is not None and not lay.stem_f32:
+                rows = ops.stats_rows(lay.geom_f, L.EPI_RAW_F32) if self.precise else ops.stats_rows(lay.geom_act)
+                if lay.stats.shape[0] != rows:
+                    lay.stats = torch.zeros(rows, 2, lay.stats.shape[2], dtype=torch.float32, device=dev)
         return wbytes
 
     def _fold_constants(self, prod, training):
@@ -989,10 +992,11 @@ class Engine:
                                 lay.stats if training else None)
                 ops.bn_coeffs(lay.stats if training else None, lay.cout, lay.M, bn.weight.data, bn.bias.data,
                               bn.running_mean, bn.running_var, training, lay.scale, lay.shift, lay.mean, lay.invstd,
-                              momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps)
+                              momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps, perm=lay.perm32,
+                              ones_channel=lay.ones_idx)
                 t, t2 = lay.out_t, lay.out2_t
-                ops.bn_act_fwd(B, lay.H, lay.W, lay.cout, lay.y, lay.cout, 0, lay.scale, lay.shift, lay.slope, lay.mode,
-                               self.bufs[t.buf], t.ld, t.choff,
+                ops.bn_act_fwd(B, lay.H, lay.W, lay.n_act if lay.bn_narrow else lay.cout, lay.y, lay.cout, 0, lay.scale, lay.shift,
+                               lay.slope, lay.mode, self.bufs[t.buf], t.ld, t.choff,
                                self.bufs[t2.buf] if t2 is not None else None,
                                t2.ld if t2 is not None else 0, t2.choff if t2 is not None else 0, border=lay.border,
                                planes=self.act_planes, dst_plane=t.ps, dst2_plane=t2.ps if t2 is not None else 0,
