@@ -9,12 +9,15 @@ driver's `python -m torch.distributed.run ... bench.py --gpus N` does) it is one
 touched the GPU, forwards the child's output and exits with its code (never an exec).  MCAMD_DP_BACKEND=gloo lets the
 ranks share one GPU (rehearsal on a 1-GPU box).
 
-One step = model(x) -> sum-of-logits loss -> backward (HIP engine) -> [gradient all-reduce]
+One step = model(x) -> mean-of-logits loss -> backward (HIP engine) -> [gradient all-reduce]
 -> torch.optim.SGD step (lr 1e-5, momentum .9, weight_decay .0005*B: reference train.py:144-147)
 on one resident synthetic batch of B=64 images per GPU (BASELINE.json configs[1]).
+The TIMED step runs in the drop-in's default operand precision (`--precision auto` = "mixed": train-mode logits within
+north_star's 1e-3 of the reference's fp32 path); a second leg times the other precision of {mixed, fp16} and `parity` checks
+both against the oracle (`config.tolerance_mode`, `config.throughput_mode`).
 Prints ONE JSON line (rank 0).  The timed region is NOT instrumented; `roofline` comes from a separate pass of a few
-more steps in which every convolution launch is bracketed by HIP events on the launch stream, for the dominant kernel:
-the implicit-GEMM MFMA convolution instance (forward + dgrad launches) with the largest total time.
+more steps in which every convolution launch is bracketed by HIP events on the launch stream (medians per launch), for
+the dominant kernel: the implicit-GEMM MFMA convolution instance of the timed engine with the largest total time.
 `cpu_baseline` is the oracle (PyTorch-CPU restatement of the reference) on the host cores (rank 0, N = 1 only).
 
 --workload prune measures the other half of the hot path: weight_prune(80) and quick_filter_prune(40)
@@ -647,6 +650,15 @@ def main():
         model.precision = args.precision
         for prec in legs:
             legs[prec]["train_logits_rel_l2"] = parity["train_logits_rel_l2_" + prec]
+    # every rank's probe result (engine.py _probe_side_stream): a rank whose second stream shares the launch stream's hardware
+    # queue runs its weight gradients serialised and would bound the whole job
+    ssc = next(iter(engine_mod.Engine._SIDE_STREAMS.values()), (None, None))[1]
+    ssc_all = [ssc]
+    if dp_on:
+        flag = torch.tensor([-1 if ssc is None else int(bool(ssc))], device=dev, dtype=torch.int32)
+        got = [torch.zeros_like(flag) for _ in range(world)]
+        dist.all_gather(got, flag)
+        ssc_all = [None if int(t.item()) < 0 else bool(int(t.item())) for t in got]
     if rank != 0:
         return
     value = world * B * args.steps / dt
@@ -707,6 +719,7 @@ def main():
     if dp_on:
         res["cpu_baseline"] = None
         res["collective"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                             "second_stream_concurrent_per_rank": ssc_all,
                              "transport": reducer.transport, "kept_fraction": round(reducer.kept_fraction, 4),
                              "bytes_per_step_per_rank": red_bytes // max(1, red_steps),
                              "collectives_per_step": red_colls // max(1, red_steps),
