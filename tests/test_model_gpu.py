@@ -187,14 +187,16 @@ def test_mini_masked_training_steps(dev):
     assert prune_rate(m, verbose=False) > 50.0
 
 
-def test_mini_masked_training_steps_split_forward(dev):
-    """The same two masked SGD steps with the forward pass on split operands (precision "fp16x3"): without the forward's
+@pytest.mark.parametrize("prec", ["fp16x3", "auto"])
+def test_mini_masked_training_steps_split_forward(dev, prec):
+    """The same two masked SGD steps with the forward pass on split operands (precision "fp16x3", and "auto" = the training
+    DEFAULT, "mixed", which leaves the costliest blocks on plain operands and compacts the masked filters): without the forward's
     fp16 noise the weight UPDATE must track the reference's golden run closely -- an absolute bar (5e-2 on the worst tensor;
     2.1e-2 measured, the second step sees the first step's update error through the train-mode network; the plain-fp16
     mode is only held to 1.5 x its 0.18 storage floor + 0.02 = 0.29), i.e. a real check of backward + SGD."""
     gold = np.load(os.path.join(HERE, "golden", "sgd_step.npz"))
     m, blocks, state = _mini_model(dev)
-    m.precision = "fp16x3"
+    m.precision = prec
     masks = [torch.from_numpy(gold["mask%d" % i]).to(dev) for i in range(7)]
     m.set_masks(masks)
     start = {n: p.detach().cpu().clone() for n, p in m.named_parameters()}
@@ -210,7 +212,7 @@ def test_mini_masked_training_steps_split_forward(dev):
         upd_ref = torch.from_numpy(gold["step1/" + name]) - start[name]
         e = rel_l2(p.detach().cpu() - start[name], upd_ref)
         worst = max(worst, e)
-    print("worst relative error of the 2-step weight update, split-operand forward: %.2e" % worst)
+    print("worst relative error of the 2-step weight update, split-operand forward (%s): %.2e" % (prec, worst))
     assert worst < 5e-2
     for p, mk in zip([p for p in m.parameters() if p.dim() == 4], masks):
         assert bool((p.detach()[mk == 0] == 0).all())
