@@ -289,11 +289,11 @@ class Engine:
         # (not in training: there the first block's operand rounding alone costs 1.9e-2 on the logits, MIXED_BUDGET_TRAIN)
         self.stem = (cin0 == 3 and first_k == 3) and (not self.precise or (self.precision == "mixed" and stem_block_ok
                                                                           and not self.for_training))
-        # "mixed" in training: the first block multiplies split operands through the generic kernels in the FORWARD pass, but
-        # its BACKWARD pass is the fused first block's (plain fp16 operands, as every backward in every mode): that one
-        # recomputes the block from the NHWC4 image, so the block's fp32 raw output (1.4 GB at B=64) is read once by the
-        # activation pass and never again, and its 0.7 GB dY never exists.  The fused forward runs too, into a scratch
-        # output, only to fill the workspace its backward reads (Gram sums) and its own self-consistent coefficients.
+        # "mixed" in training: the first block is the fused unit on SPLIT operands in the forward pass (two passes over the
+        # hi / lo NHWC4 images, section 3e of DESIGN.md), and its BACKWARD pass is the fused first block's on plain fp16
+        # operands, as every backward in every mode: that one recomputes the block from the NHWC4 hi image, so neither the
+        # block's raw output nor its dY ever exists.  Its Gram context and self-consistent coefficients come from the
+        # statistics half of the plain block (mcamd_stem_block_fwd with dst = NULL).
         self.stem_shadow = bool(self.precise and self.for_training and not self.stem and stem_block_ok)
         ld0 = 4 if self.stem else ops.round_up(cin0 * (3 if self.precise else 1), 32)
         place[-1] = _T(new_buf(B, H0, W0, ld0), ld0, 0, cin0, H0, W0, cin0 if (self.precise and not self.stem) else 0)
@@ -440,16 +440,13 @@ class Engine:
             # recomputed and written once as the pooled hi | lo planes (csrc/conv_stem_block.hip, SPLIT).  Replaces the fp32
             # first convolution's 1.4 GB raw output, its BatchNorm pass and the scratch forward of the plain block:
             # 1.16 -> 0.41 ms per B=64 step (13.85 -> 12.98 ms, A/B on one box).
-            lay.stem_split = bool(lay.stem_shadow)
+            lay.stem_split = lay.stem_shadow      # (one property since round 4: forward on split operands, backward the plain block's)
             if lay.stem_shadow:
                 lay.sh_img = ops.alloc_padded(B, lay.H, lay.W, 4, dev)                    # NHWC4 fp16 image
                 lay.sh_geom = ops.geom(B, lay.H, lay.W, 3, 3, lay.cout, 4, 0, 1)
                 lay.sh_wp = torch.zeros(ops.packed_elems(lay.sh_geom)[0], dtype=ops.HALF, device=dev)
-                if lay.stem_split:
-                    lay.sh_img_lo = ops.alloc_padded(B, lay.H, lay.W, 4, dev)             # fp16(x - fp16(x))
-                    lay.sh_wp_lo = torch.zeros_like(lay.sh_wp)
-                else:
-                    lay.sh_dst = ops.alloc_padded(B, lay.H // 2, lay.W // 2, 32, dev)      # scratch pooled output
+                lay.sh_img_lo = ops.alloc_padded(B, lay.H, lay.W, 4, dev)                 # fp16(x - fp16(x))
+                lay.sh_wp_lo = torch.zeros_like(lay.sh_wp)
                 lay.sh_coef = [torch.empty(lay.cout, **f32) for _ in range(4)]             # scale, shift, mean, invstd
                 lay.stem_ws = torch.empty(ops.stem_block_workspace_bytes(), dtype=torch.uint8, device=dev)
             lay.dy = None if (lay.fused_stem or lay.stem_shadow) else ops.alloc_padded(B, lay.H, lay.W, lay.cout_p, dev, pad=lay.pad)
@@ -634,8 +631,6 @@ class Engine:
                 ops.pack_weights(lay.geom_act, lay.conv.weight.data, mask, True, False, lay.wp, None, rows=lay.g_rows)
             if getattr(lay, "stem_split", False):          # hi and lo stem packings of the split-operand fused first block
                 ops.pack_stem_split(lay.conv.weight.data, mask, lay.sh_wp, lay.sh_wp_lo)
-            elif getattr(lay, "stem_shadow", False):
-                ops.pack_weights(lay.sh_geom, lay.conv.weight.data, mask, True, False, lay.sh_wp, None)
         # The layers behind the first block are not needed until that block's forward is done: with folded layers
         # (filter masks) their fold + re-pack runs on the second stream under the first block's Gram / forward kernels and
         # forward() makes the launch stream wait for it in front of the second block (self._pack_event): 7.17 -> 7.10 ms
@@ -902,7 +897,7 @@ class Engine:
             elif l0.stem_f32:
                 # the first convolution in fp32 from the image itself (outside the recorded plan: the image pointer is
                 # the caller's); the hi plane of the image is still needed where the generic weight gradient reads it
-                if training and not l0.stem_shadow:
+                if training:
                     ops.nchw_to_padded_split(xs, self.bufs[tin.buf], tin.ld, tin.choff, tin.ps)
                 mask0 = l0.conv.mask if l0.conv.mask_flag else None
                 self._timed('fwd', l0, ops.stem_conv_f32, xs, l0.conv.weight.data, mask0, l0.weff, l0.y, l0.cout,
@@ -912,8 +907,6 @@ class Engine:
                 # (written by the layout kernel itself: round 2 built the planes with torch.cat, three 3 x B x H x W fp32
                 # temporaries per forward -- 0.8 GB at B=128 through the caching allocator)
                 ops.nchw_to_padded_split(xs, self.bufs[tin.buf], tin.ld, tin.choff, tin.ps)
-            if training and l0.stem_shadow and not l0.stem_split:
-                ops.nchw_to_padded(xs, l0.sh_img, 4, 0)
         else:
             ops.nchw_to_padded(xs, self.bufs[tin.buf], tin.ld, tin.choff)
         if self._logits is None:
@@ -977,13 +970,6 @@ class Engine:
                                    momentum=0.0, eps=bn.eps, cout=lay.cout, planes=1)
                 self._timed('fwd', lay, self._stem_split_forward, lay)
                 continue
-            if training and lay.stem_shadow:
-                # the fused first block on plain operands into a scratch output: fills the workspace and the coefficients
-                # its backward pass reads (no running-statistics update: the split path below owns them)
-                c = lay.sh_coef
-                ops.stem_block_fwd(B, lay.H, lay.W, lay.sh_img, lay.sh_wp, bn.weight.data, bn.bias.data, None, None, True,
-                                   c[0], c[1], c[2], c[3], lay.slope, lay.sh_dst, 32, 0, lay.stem_ws,
-                                   momentum=0.0, eps=bn.eps, cout=lay.cout, planes=1)
             if self.precise:
                 # unrounded fp32 raw output (+ batch statistics from the fp32 values), then BN + LeakyReLU
                 # (+ pool / reorg / route) written as hi | lo | hi planes
