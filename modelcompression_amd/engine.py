@@ -373,7 +373,7 @@ class Engine:
                 self.producer_of[lay.out_id] = lay
                 if lay.out2_id is not None:
                     self.producer_of[lay.out2_id] = lay
-            lay.fold, lay.ones_idx, lay.skip_dead, lay.fold_consumers, lay.bn_narrow = None, -1, False, [], False
+            lay.fold, lay.ones_idx, lay.skip_dead, lay.fold_consumers, lay.bn_width = None, -1, False, [], 0
         # a concat tensor's members are consumed through the concat's consumer
         self.consumer_of = {}
         for lay in self.layers:
@@ -777,7 +777,7 @@ class Engine:
         Returns the weight-gradient workspace bytes the new geometries need."""
         dev = self.device
         for lay in self.layers:
-            lay.fold, lay.ones_idx, lay.skip_dead, lay.fold_consumers, lay.bn_narrow = None, -1, False, [], False
+            lay.fold, lay.ones_idx, lay.skip_dead, lay.fold_consumers, lay.bn_width = None, -1, False, [], 0
             lay.waug = lay.dwaug = None
             self._fold_key = None
             if lay.gin is not None:
@@ -803,31 +803,48 @@ class Engine:
             # folding must remove at least a quarter of the input channels to pay for its ragged tiles (measured on
             # conv19 of the 40 % model, 840 of 1024 channels: dgrad 0.188 -> 0.294 ms)
             aug = ops.round_up(prod.n_act + 1, 64 if prod.cout >= 256 else (32 if self.precise else 8))
-            if aug > 0.75 * prod.cout:
-                continue
-            # BatchNorm / activation passes on the kept channels only (their kernels keep one 8-channel group per thread:
-            # 8 x a power of two channels); the ones-channel is then written once, here, instead of by every forward pass
+            # BatchNorm / activation passes of a folded producer on fewer channels (their kernels keep one 8-channel group per
+            # thread: 8 x a power of two channels).  EXACT: the kept count itself is such a number -- the pass covers the kept
+            # channels and the ones-channel behind them is written once, here.  WIDENED (round 4): otherwise the next such
+            # number that holds kept + ones -- the pass then writes the ones-channel itself (scale 0 / shift 1) and, behind it,
+            # dead channels as the constants they are, which meet zero columns of the augmented weights.  0 = full width.
             ch = prod.n_act // 8
-            narrow = prod.n_act % 8 == 0 and ch >= 1 and (ch & (ch - 1)) == 0 and ch <= 256 and self.bn_narrow_on
-            if self.precise and not narrow:
+            exact = prod.n_act % 8 == 0 and ch >= 1 and (ch & (ch - 1)) == 0 and ch <= 256
+            width = prod.n_act if exact else 0
+            if not exact:
+                w2 = 8
+                while w2 < prod.n_act + 1:
+                    w2 *= 2
+                if w2 < prod.cout and w2 <= 2048:
+                    width = w2
+            if not self.bn_narrow_on:
+                width = 0
+            if self.precise:
                 # Split-operand engines store a tensor as hi | lo planes; a folding consumer's K-concatenated geometry wants
-                # them `aug` channels apart (x_wrap = 2 aug), so the producer's activation pass must write `aug`-spaced planes
-                # -- which only works when it writes the kept channels alone (a full-width pass would overlap its own lo
-                # plane).  Producers whose kept count is not 8 x a power of two stay compacted but unfolded here.
+                # them `aug` channels apart (x_wrap = 2 aug), so the producer's activation pass writes `aug`-spaced planes --
+                # which only works when it is a narrowed pass that fits under the plane pitch (a full-width pass would run over
+                # its own lo plane).  Producers without one stay compacted but unfolded.
+                if not width:
+                    continue
+                aug = max(aug, width)
+            elif width and aug > width and not exact:
+                width = 0                 # (the consumer would read channels the narrowed pass does not write)
+            if aug > 0.75 * prod.cout:
                 continue
             prod.ones_idx, prod.skip_dead = prod.n_act, True
             prod.fold_consumers = sorted(cons, key=lambda c: -c.li)      # backward order: the first one initialises dbeta
-            prod.bn_narrow = narrow
-            if prod.bn_narrow:
+            prod.bn_width = width
+            if width:
                 for t in (prod.out_t, prod.out2_t):
                     if t is not None:
                         v = ops.padded_view(self.bufs[t.buf], self.B, t.H, t.W, t.ld)[:, 1:-1, 1:-1]
                         if self.precise:                 # both planes: aug apart from now on, zero but for the ones-channel
                             t.ps = aug
                             v[..., t.choff:t.choff + 2 * t.C] = 0
-                        else:
+                        elif exact:
                             v[..., t.choff + prod.n_act + 1:t.choff + prod.cout] = 0
-                        v[..., t.choff + prod.n_act] = 1
+                        if exact:
+                            v[..., t.choff + prod.n_act] = 1
                 prod.dy.zero_()
             for c in cons:
                 c.fold = prod
@@ -981,7 +998,7 @@ class Engine:
                               momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps, perm=lay.perm32,
                               ones_channel=lay.ones_idx)
                 t, t2 = lay.out_t, lay.out2_t
-                ops.bn_act_fwd(B, lay.H, lay.W, lay.n_act if lay.bn_narrow else lay.cout, lay.y, lay.cout, 0, lay.scale, lay.shift,
+                ops.bn_act_fwd(B, lay.H, lay.W, lay.bn_width or lay.cout, lay.y, lay.cout, 0, lay.scale, lay.shift,
                                lay.slope, lay.mode, self.bufs[t.buf], t.ld, t.choff,
                                self.bufs[t2.buf] if t2 is not None else None,
                                t2.ld if t2 is not None else 0, t2.choff if t2 is not None else 0, border=lay.border,
@@ -1008,7 +1025,7 @@ class Engine:
                           momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps, perm=lay.perm32,
                           ones_channel=lay.ones_idx)
             t, t2 = lay.out_t, lay.out2_t
-            ops.bn_act_fwd(B, lay.H, lay.W, lay.n_act if lay.bn_narrow else lay.cout, lay.y, lay.cout, 0, lay.scale, lay.shift,
+            ops.bn_act_fwd(B, lay.H, lay.W, lay.bn_width or lay.cout, lay.y, lay.cout, 0, lay.scale, lay.shift,
                            lay.slope, lay.mode, self.bufs[t.buf], t.ld, t.choff,
                            self.bufs[t2.buf] if t2 is not None else None,
                            t2.ld if t2 is not None else 0, t2.choff if t2 is not None else 0, border=lay.border,
@@ -1031,7 +1048,7 @@ class Engine:
         """pool / reorg / route + LeakyReLU + BatchNorm backward of one block: G (gradient wrt the block's output, at the
         consumer's channel slice) -> dY (padded NHWC), dgamma, dbeta.  One place for the launch arguments (narrowed to the
         kept channels for a folded producer); tests re-issue it with a substitute G."""
-        cb = lay.n_act if lay.bn_narrow else lay.cout
+        cb = lay.bn_width or lay.cout
         act = {}
         if self.bwd_from_act and self.precise and lay.mode == L.DST_PLAIN and g2 is None:
             # split-operand engines save y as fp32: a PLAIN block's two backward passes read the stored activation (the hi
