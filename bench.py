@@ -546,17 +546,20 @@ def main():
         fl = eng.conv_flops(lay)                       # ALGORITHMIC flops: 2 M Cout Cin k^2 of the reference's convolution
         avg = ms / n
         # a split-operand forward launch multiplies the K-concatenated problem: `level` MFMA products per algorithmic one
-        level = lay.level if (tag == "fwd" and eng.precise) else 1
+        # (fp8-correction form, lay.f8: one fp16 product + two e4m3 products at twice the rate = 2 fp16-equivalent products)
+        level = (2 if getattr(lay, "f8", False) else lay.level) if (tag == "fwd" and eng.precise) else 1
         tile = None
         if tag != "wgrad" and not (li == 0 and (lay.fused_stem or getattr(lay, "stem_split", False))):
             g_ = lay.geom_f if (tag == "fwd" and eng.precise) else lay.geom_act
             epi = (1 if lay.is_last else (3 if eng.precise else 0)) if tag == "fwd" else 0
-            tile = ops.tile_info(g_, dgrad=(tag == "dgrad")) + (epi,)   # (the instrumented pass runs every launch alone)
+            f8 = 1 if (tag == "fwd" and getattr(lay, "f8", False)) else 0
+            tile = ops.tile_info(g_, dgrad=(tag == "dgrad")) + (epi, f8)   # (the instrumented pass runs every launch alone)
         tot[tag][0] += avg
         tot[tag][1] += fl
         rows.append("%-6s conv%-2d %4dx%-4d cin %4d cout %4d k%d  %8.3f ms  %8.1f TFLOP/s%s  tile %s" % (
             tag, li + 1, lay.H, lay.W, lay.cin, lay.cout, lay.k, avg, fl / avg / 1e9,
-            (" (x%d MFMA products: %.1f executed)" % (level, level * fl / avg / 1e9)) if level > 1 else "", tile))
+            (" (x%d %s: %.1f executed)" % (level, "fp16-equivalent MFMA products, fp16 + 2 fp8" if getattr(lay, "f8", False) and tag == "fwd"
+                                           else "MFMA products", level * fl / avg / 1e9)) if level > 1 else "", tile))
         if tile is not None:
             b = by_tile.setdefault(tile, [0.0, 0.0, 0, 0.0])
             b[0] += ms
@@ -576,7 +579,7 @@ def main():
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
-            want = {2: "void igemm_pp_kernel<%d, %d, %d," % (dom_tile[4], dom_tile[0], dom_tile[1])}.get(
+            want = {2: "void igemm_pp_kernel<%d, %d, %d, %s>" % (dom_tile[4], dom_tile[0], dom_tile[1], "32, true" if dom_tile[5] else "16, false")}.get(
                 dom_tile[3], "void igemm_kernel<%d, %d," % dom_tile[:2])
             if tj["kernel"].startswith(want):
                 traffic = round(tj["hbm_bytes_per_launch"])
@@ -600,8 +603,11 @@ def main():
              "ms_per_step": round(seconds / args.steps * 1e3, 3)}
         if prec == "mixed":
             d["plain_fp16_blocks"] = [l.li + 1 for l in e_.layers if l.level == 1]
-            d["note"] = ("forward convolutions on split hi/lo fp16 operands (3 MFMA products per multiply, fp32 raw outputs) "
-                         "except the listed blocks; the first block fused on split operands; backward on plain fp16 operands")
+            d["fp8_correction_blocks"] = [l.li + 1 for l in e_.layers if getattr(l, "f8", False)]
+            d["note"] = ("forward convolutions on split operands with fp32 raw outputs: x_hi*w_hi on fp16 MFMAs plus the correction "
+                         "products x_lo*w_hi + x_hi*w_lo -- from e4m3 copies on block-scaled fp8 MFMAs in `fp8_correction_blocks`, "
+                         "from fp16 lo planes in the other split blocks; `plain_fp16_blocks` multiply x_hi*w_hi only; the first "
+                         "block fused on split operands; backward on plain fp16 operands")
         else:
             d["note"] = "plain fp16 MFMA operands everywhere: its train-mode logits do NOT meet 1e-3 (see `parity`)"
         return d
@@ -690,12 +696,14 @@ def main():
         "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_gflop_per_launch": round(dom_flop / max(dom_n, 1) / 1e9, 2),
-                     # split-operand launches execute 3 MFMA products per algorithmic multiply: the rate the matrix cores
-                     # actually ran at (achieved counts the reference's 2 M N K only, as the contract asks)
+                     # split-operand launches execute 3 MFMA products per algorithmic multiply -- one fp16 + two fp8 at twice
+                     # the rate (= 2 fp16-equivalent products) in the fp8-correction form: the rate the matrix cores actually
+                     # ran at, in fp16-equivalent flops (achieved counts the reference's 2 M N K only, as the contract asks)
                      "mfma_tflops_executed": round(executed, 1), "mfma_frac_executed": round(executed / PEAK_FP16_TFLOPS, 4),
-                     "kernel": ("igemm_pp_kernel<%d,%d,%d,16> %dx%dx%d ping-pong (%s launches of that instance)" % (
-                                    (dom_tile[4],) + dom_tile[:2] + dom_tile[:3] +
-                                    ("split-operand conv forward, fp32 raw output" if dom_tile[4] == 3 else "conv fwd + dgrad",))
+                     "kernel": ("igemm_pp_kernel<%d,%d,%d,%s> %dx%dx%d ping-pong (%s launches of that instance)" % (
+                                    (dom_tile[4],) + dom_tile[:2] + ("32,true" if dom_tile[5] else "16",) + dom_tile[:3] +
+                                    (("split-operand conv forward with fp8 correction terms, fp32 raw output" if dom_tile[5] else
+                                      "split-operand conv forward, fp32 raw output") if dom_tile[4] == 3 else "conv fwd + dgrad",))
                                 if dom_tile[3] == 2 else
                                 "igemm_kernel<%d,%d,..,%d,2,%d> (conv launches of that instance)" % (dom_tile[:3] + (dom_tile[4],))),
                      "launches_per_step": dom_n // nprof,

@@ -83,7 +83,17 @@ typedef struct mcamd_conv_geom {
                              x_wrap = 2 P: the third part multiplies the hi plane again without a third copy of it.
                              P % 32 == 0; epilogue modes MCAMD_EPI_RAW_F32 / MCAMD_EPI_NCHW_F32; the buffer slice must hold
                              x_wrap channels. */
+    int32_t x_f8;         /* mcamd_conv_fwd only, 0 = none.  P > 0 (P % 64 == 0, cin = 2 P, x_wrap = 0): the split-operand forward
+                             with fp8 CORRECTION terms.  Channels [0, P) of the slice are the fp16 hi plane; the next P fp16
+                             units hold 2 P OCP-e4m3 bytes [lo8 = e4m3(x_lo * 2^12) | x8 = e4m3(x * 2)] (mcamd_act_desc.planes 4),
+                             the packed weights [w_hi | w8 = e4m3(w_hi * 2^5) | wlo8 = e4m3(w_lo * 2^16)] (mcamd_pack_job.split 2):
+                             y = x_hi w_hi (fp16 MFMA) + 2^-17 (lo8 w8 + x8 wlo8) (block-scaled fp8 MFMA at twice the fp16
+                             rate, same fp32 accumulators) -- x w to ~2^-15 instead of plain fp16's 2^-11, at 2/3 of the
+                             x_wrap form's MFMA time and staged bytes.  Epilogue mode MCAMD_EPI_RAW_F32; only shapes for
+                             which mcamd_conv_fwd_f8_ok() returns 1 (the ping-pong implicit-GEMM tiles).  Replaces the same
+                             F.conv2d (reference src/pruning/weightPruning/layers.py:60-64). */
 } mcamd_conv_geom;
+int32_t mcamd_conv_fwd_f8_ok(const mcamd_conv_geom* g);   /* 1: mcamd_conv_fwd accepts this x_f8 geometry */
 
 /* Output side of a convolution launch. */
 #define MCAMD_EPI_RAW_F16 0   /* y: fp16 [M][y_ld] + optional per-channel partial sums (BN batch statistics) */
@@ -182,7 +192,9 @@ typedef struct mcamd_pack_job {
                                   "mixed" precisions, [w_hi | w_hi | w_lo] along the input channels of a 3 * cin wide row
                                   (w_hi = fp16(w * mask), w_lo = fp16(w * mask - w_hi)), to be multiplied with
                                   [x_hi | x_lo | x_hi] activation planes; dst_fwd then has the size of a geometry with
-                                  3 * cin input channels.  The dgrad packing is plain in both cases. */
+                                  3 * cin input channels.  2: the fp8-correction packing of mcamd_conv_geom.x_f8,
+                                  [w_hi fp16 | w8 | wlo8 e4m3 bytes] in a row of 2 * cin fp16 units per tap (cin % 64 == 0).
+                                  The dgrad packing is plain in every case. */
 } mcamd_pack_job;
 int mcamd_pack_weights_many(const mcamd_pack_job* jobs_dev, int32_t njobs, int64_t total_tiles, void* stream);
 
@@ -260,7 +272,9 @@ typedef struct mcamd_act_desc {
                                   1e-3 logits (tools/error_budget.py).  Reading channels [0, C) alone is the plain
                                   fp16 activation.
                                   2 = hi and lo only: the consumer reads the hi plane twice (mcamd_conv_geom.x_wrap),
-                                  4 instead of 6 bytes written per activation. */
+                                  4 instead of 6 bytes written per activation.
+                                  4 = hi and, one plane stride further, the e4m3 correction bytes [lo8 | x8] of a consumer
+                                  with mcamd_conv_geom.x_f8 (each `plane` BYTES long; fp32 y only). */
     int32_t dst_plane, dst2_plane; /* plane strides (channels, multiples of 8) of dst / dst2 when planes >= 2 */
     int32_t dst_pad, dst2_pad; /* 0 / 1: dst, dst2 are in the padded / the shared-halo form (each at its own resolution) */
     const float* border;       /* optional fp32 [16][C], NULL = none: added to the raw conv output before the
@@ -269,6 +283,8 @@ typedef struct mcamd_act_desc {
                                   constant output of their removed input channels into this table, because zero
                                   padding clips it differently at the borders (BASELINE config 5; the reference
                                   only states slim convs as a conclusion, README.md:19). */
+    int32_t planes2;           /* storage form of dst2 when it differs from dst's (its consumer is another convolution);
+                                  0 = `planes` */
 } mcamd_act_desc;
 int mcamd_bn_act_fwd(const mcamd_act_desc* d, void* stream);
 

@@ -17,7 +17,7 @@ class McamdError(RuntimeError):
 class ConvGeom(C.Structure):
     _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("ksize", C.c_int32),
                 ("cin", C.c_int32), ("cout", C.c_int32), ("x_ld", C.c_int32), ("x_choff", C.c_int32),
-                ("stem", C.c_int32), ("pad", C.c_int32), ("x_wrap", C.c_int32)]
+                ("stem", C.c_int32), ("pad", C.c_int32), ("x_wrap", C.c_int32), ("x_f8", C.c_int32)]
 
 
 class ConvEpilogue(C.Structure):
@@ -36,7 +36,7 @@ class ActDesc(C.Structure):
                 ("dst", C.c_void_p), ("dst_ld", C.c_int32), ("dst_choff", C.c_int32),
                 ("dst2", C.c_void_p), ("dst2_ld", C.c_int32), ("dst2_choff", C.c_int32),
                 ("y_dtype", C.c_int32), ("planes", C.c_int32), ("dst_plane", C.c_int32), ("dst2_plane", C.c_int32),
-                ("dst_pad", C.c_int32), ("dst2_pad", C.c_int32), ("border", C.c_void_p)]
+                ("dst_pad", C.c_int32), ("dst2_pad", C.c_int32), ("border", C.c_void_p), ("planes2", C.c_int32)]
 
 
 class ChanMap(C.Structure):
@@ -108,6 +108,7 @@ SIGNATURES = {
     "mcamd_reload_config": (None, []),
     "mcamd_conv_stats_rows": (_I32, [C.POINTER(ConvGeom)]),
     "mcamd_conv_stats_rows_mode": (_I32, [C.POINTER(ConvGeom), _I32]),
+    "mcamd_conv_fwd_f8_ok": (_I32, [C.POINTER(ConvGeom)]),
     "mcamd_conv_tile_info": (C.c_int, [C.POINTER(ConvGeom), _I32, C.POINTER(_I32)]),
     "mcamd_packed_elems_fwd": (_I64, [C.POINTER(ConvGeom)]),
     "mcamd_packed_elems_dgrad": (_I64, [C.POINTER(ConvGeom)]),

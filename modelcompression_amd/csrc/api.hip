@@ -61,6 +61,10 @@ static int check_geom(const mcamd_conv_geom* g, const char* what) {
         MCAMD_REQUIRE(g->x_choff + span <= g->x_ld, "%s: x channel slice [%d, %d) exceeds x_ld %d", what,
                       g->x_choff, g->x_choff + span, g->x_ld);
     }
+    if (g->x_f8 != 0) {
+        MCAMD_REQUIRE(!g->stem && g->x_wrap == 0 && g->x_f8 > 0 && g->x_f8 % 64 == 0 && g->cin == 2 * g->x_f8,
+                      "%s: x_f8 %d needs cin = 2 P with P %% 64 == 0, no x_wrap (cin %d)", what, g->x_f8, g->cin);
+    }
     if (g->x_wrap != 0) {
         const int ct = cin_tap_of(g), kb = ct % 64 == 0 ? 64 : 32;   // kblock_of(ct)
         MCAMD_REQUIRE(!g->stem && g->x_wrap > 0 && g->x_wrap % 64 == 0 && g->x_wrap % kb == 0 && g->cin == g->x_wrap / 2 * 3 && ct == g->cin,
@@ -285,7 +289,43 @@ __global__ __launch_bounds__(256) void pack_tiles_kernel(const mcamd_pack_job* j
         // 2. forward layout [n][kpos(t, c)]: 8 consecutive channels of one (filter, tap) per lane = one 16-byte store.
         // j.split: the split-operand packing [w_hi | w_hi | w_lo] along the input channels (w_hi = fp16(w * mask),
         // w_lo = fp16(w * mask - w_hi)), i.e. channel c is written at c, cin + c and 2 cin + c of a 3 cin wide row.
-        if (j.dst_fwd) {
+        if (j.dst_fwd && j.split == 2) {
+            // fp8 correction packing (mcamd_conv_geom.x_f8): a row of 2 cin fp16 units per tap = [w_hi: cin fp16 | w8: cin
+            // e4m3 bytes | wlo8: cin bytes], the byte string cut into the same [channel block][tap][64] K order as the
+            // activations' [x_hi | lo8 | x8].  cin % 64 == 0 (host-checked).
+            half_t* dst = (half_t*)j.dst_fwd;
+            const int cin_tap = 2 * j.cin;
+            for (int e = threadIdx.x; e < TS * kk * (TS / 8); e += 256) {
+                const int g8 = e % (TS / 8), t = (e / (TS / 8)) % kk, nl = e / ((TS / 8) * kk);
+                const int n = n0 + nl, c = c0 + g8 * 8;
+                if (n >= j.cout || c >= j.cin) continue;
+                const float* src = tile + nl * LDW + (g8 * 8) * kk + t;
+                half_t* row = dst + (long long)n * kk * cin_tap;
+                h8_t h;
+                float q8[8], ql[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float v = src[i * kk];
+                    h[i] = (half_t)v;
+                    q8[i] = fminf(fmaxf((float)h[i] * (float)(1 << MCAMD_F8_SW8), -448.f), 448.f);
+                    ql[i] = fminf(fmaxf((v - (float)h[i]) * (float)(1 << MCAMD_F8_SWL), -448.f), 448.f);
+                }
+                *(h8_t*)(row + kpos(t, c, kk, cin_tap)) = h;
+                int w8[2], wl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    w8[i] = __builtin_amdgcn_cvt_pk_fp8_f32(q8[4 * i], q8[4 * i + 1], 0, false);
+                    w8[i] = __builtin_amdgcn_cvt_pk_fp8_f32(q8[4 * i + 2], q8[4 * i + 3], w8[i], true);
+                    wl[i] = __builtin_amdgcn_cvt_pk_fp8_f32(ql[4 * i], ql[4 * i + 1], 0, false);
+                    wl[i] = __builtin_amdgcn_cvt_pk_fp8_f32(ql[4 * i + 2], ql[4 * i + 3], wl[i], true);
+                }
+                // e4m3 element e of the tap's [w8 | wlo8] string lives in byte (e & 1) of fp16 unit cin + e / 2
+                int* d8 = (int*)(row + kpos(t, j.cin + c / 2, kk, cin_tap));
+                d8[0] = w8[0], d8[1] = w8[1];
+                int* dl = (int*)(row + kpos(t, j.cin + (j.cin + c) / 2, kk, cin_tap));
+                dl[0] = wl[0], dl[1] = wl[1];
+            }
+        } else if (j.dst_fwd) {
             half_t* dst = (half_t*)j.dst_fwd;
             const int parts = j.split ? 3 : 1;
             const int cin_tap = round_up_dev(j.cin * parts, 32);
@@ -434,15 +474,26 @@ extern "C" int32_t mcamd_conv_stats_rows_mode(const mcamd_conv_geom* g, int32_t 
         if (g->pad == 0 && mcamd_small3x3_split_ok((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g), ntaps_of(g) * cin_tap_of(g),
                                                    g->x_wrap, mode))
             return mcamd_small3x3_rows((long long)g->B * g->H * g->W);
-        return mcamd_igemm_rows((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g), ntaps_of(g) * cin_tap_of(g), false);
+        const int ct = g->x_f8 > 0 ? cin_tap_of(g) / 2 * 3 : cin_tap_of(g);      // (x_f8: the tile of the three-product problem)
+        return mcamd_igemm_rows((long long)g->B * g->H * g->W, g->cout, ct, ntaps_of(g) * ct, false);
     }
     return mcamd_conv_stats_rows(g);
+}
+
+extern "C" int32_t mcamd_conv_fwd_f8_ok(const mcamd_conv_geom* g) {
+    if (!g || g->x_f8 <= 0 || g->x_f8 % 64 != 0 || g->cin != 2 * g->x_f8 || g->stem || g->x_wrap != 0) return 0;
+    return mcamd_igemm_f8_ok((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g), ntaps_of(g) * cin_tap_of(g)) ? 1 : 0;
 }
 
 extern "C" int mcamd_conv_tile_info(const mcamd_conv_geom* g, int32_t dgrad, int32_t out[4]) {
     if (check_geom(g, "conv_tile_info")) return MCAMD_EINVAL;
     MCAMD_REQUIRE(out, "conv_tile_info: null output");
     out[3] = 0;
+    if (!dgrad && g->x_f8 > 0) {
+        const int ct = cin_tap_of(g) / 2 * 3;
+        mcamd_igemm_tile((long long)g->B * g->H * g->W, g->cout, ct, ntaps_of(g) * ct, out, false);
+        return MCAMD_OK;
+    }
     if (!dgrad && mcamd_stem_direct_ok(g->stem, g->cout, MCAMD_EPI_RAW_F16)) {
         out[0] = 32, out[1] = g->cout, out[2] = 48, out[3] = 1;   // stem_fwd_kernel (conv_stem.hip)
         return MCAMD_OK;
@@ -490,14 +541,21 @@ extern "C" int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const voi
     a.wrap = g->x_wrap > 0 ? g->x_wrap : 0x7fffffff;
     MCAMD_REQUIRE(g->x_wrap == 0 || (epi && (epi->mode == MCAMD_EPI_RAW_F32 || epi->mode == MCAMD_EPI_NCHW_F32)),
                   "conv_fwd: x_wrap goes with the fp32 epilogues (modes 3 and 1)");
+    // x_f8: channel blocks [P, 2 P) of the slice are e4m3 bytes; K order [channel block][tap][kb] -> the fp8 chunks are the tail
+    a.f8_from = g->x_f8 > 0 ? (g->x_f8 / a.kb) * a.ntaps * (a.kb / 32) : 0x7fffffff;
+    if (g->x_f8 > 0) {
+        MCAMD_REQUIRE(epi && epi->mode == MCAMD_EPI_RAW_F32, "conv_fwd: x_f8 goes with the fp32 epilogue (mode 3)");
+        MCAMD_REQUIRE(mcamd_igemm_f8_ok(a.M, g->cout, a.cin_tap, a.ktot), "conv_fwd: no fp8-correction kernel for this shape (mcamd_conv_fwd_f8_ok)");
+    }
     const bool stem_direct = epi && mcamd_stem_direct_ok(g->stem, g->cout, epi->mode);
-    const bool wres = epi && epi->dst_mode == MCAMD_DST_PLAIN && g->pad == 0 &&
+    const bool wres = epi && epi->dst_mode == MCAMD_DST_PLAIN && g->pad == 0 && g->x_f8 == 0 &&
                       mcamd_wres_ok(g->ksize, g->stem, g->cout, a.cin_tap, a.ktot, g->B, g->H, g->W, epi->mode);
-    const bool small_split = epi && g->pad == 0 && !g->stem && g->x_choff == 0 &&
+    const bool small_split = epi && g->pad == 0 && !g->stem && g->x_choff == 0 && g->x_f8 == 0 &&
                              mcamd_small3x3_split_ok(a.M, g->cout, a.cin_tap, a.ktot, g->x_wrap, epi->mode);
     if (fill_epilogue(a, epi, g->cout, a.M, a.cin_tap, a.ktot, "conv_fwd",
                       stem_direct ? mcamd_stem_rows(a.M) : (wres ? mcamd_wres_rows(g->cout, g->B, g->H, g->W)
-                                                                 : (small_split ? mcamd_small3x3_rows(a.M) : -1))))
+                                                                 : (small_split ? mcamd_small3x3_rows(a.M)
+                                                                                : (g->x_f8 > 0 ? mcamd_conv_stats_rows_mode(g, MCAMD_EPI_RAW_F32) : -1)))))
         return MCAMD_EINVAL;
     if (small_split) return mcamd_small3x3_split_launch(a, (hipStream_t)stream);   // conv_small.hip: weights resident, split operands
     if (wres) return mcamd_wres_launch(a, g->B, (hipStream_t)stream);
@@ -520,7 +578,7 @@ extern "C" int mcamd_conv_dgrad(const mcamd_conv_geom* g, const void* dy, int32_
         return mcamd_rec_push(stream, [=](void* s) { return mcamd_conv_dgrad(&g_, dy, dy_ld, dy_choff, wp_dgrad, &e_, s); });
     }
     if (check_geom(g, "conv_dgrad")) return MCAMD_EINVAL;
-    MCAMD_REQUIRE(g->x_wrap == 0, "conv_dgrad: x_wrap is a forward-only field");
+    MCAMD_REQUIRE(g->x_wrap == 0 && g->x_f8 == 0, "conv_dgrad: x_wrap / x_f8 are forward-only fields");
     MCAMD_REQUIRE(!g->stem, "conv_dgrad: the stem layer has no input gradient");
     MCAMD_REQUIRE(dy && wp_dgrad, "conv_dgrad: null input");
     int cout_p = cout_p_of(g);
@@ -539,6 +597,7 @@ extern "C" int mcamd_conv_dgrad(const mcamd_conv_geom* g, const void* dy, int32_
     a.N = g->cin;
     a.cin_tap = cout_p;
     a.wrap = 0x7fffffff;
+    a.f8_from = 0x7fffffff;
     a.ntaps = g->ksize * g->ksize;
     a.kb = kblock_of(a.cin_tap);
     a.ktot = a.ntaps * a.cin_tap;
@@ -582,7 +641,7 @@ extern "C" int mcamd_conv_wgrad(const mcamd_conv_geom* g, const void* x, const v
         });
     }
     if (check_geom(g, "conv_wgrad")) return MCAMD_EINVAL;
-    MCAMD_REQUIRE(g->x_wrap == 0, "conv_wgrad: x_wrap is a forward-only field");
+    MCAMD_REQUIRE(g->x_wrap == 0 && g->x_f8 == 0, "conv_wgrad: x_wrap / x_f8 are forward-only fields");
     MCAMD_REQUIRE(x && dy && dw_oihw && workspace, "conv_wgrad: null argument");
     MCAMD_REQUIRE(grad_scale > 0.f, "conv_wgrad: grad_scale must be positive");
     const int* rmap = map ? (const int*)map->rows : nullptr;

@@ -103,6 +103,7 @@ struct ActArgs {
     const float* border;  // optional [16][C]: added to the raw conv output by border class (slim models)
     int dst_plane, dst2_plane;  // plane strides of the split (hi | lo | hi) storage, PL == 3
     int dst_pw, dst2_pw;        // halo pixels per row / rows per image of dst, dst2: 2 (padded form) or 1 (shared-halo form)
+    int dst2_pl;                // storage form of dst2 (mcamd_act_desc.planes2)
 };
 
 __device__ __forceinline__ void load8(const half_t* p, float* v) {
@@ -135,19 +136,51 @@ __device__ __forceinline__ void load_y(const void* y, long long idx, float* v) {
 }
 // activation store: one fp16 plane, or the split form of the "fp16x3" precision mode (include/mcamd.h,
 // mcamd_act_desc.planes): hi = fp16(v), lo = fp16(v - hi), and hi again, `plane` channels apart
+// PL == 4 (round 4): hi = fp16(v) and, `plane` fp16 units further, the e4m3 correction bytes of the consumer with
+// mcamd_conv_geom.x_f8: [lo8 = e4m3((v - hi) * 2^12) : plane bytes | x8 = e4m3(v * 2) : plane bytes] (common.h); `ci` =
+// channel of v[0] in the buffer (the consumer's slice starts at channel 0: a concat member writes at its offset inside the
+// e4m3 strings too).  The conversion instruction returns NaN above 448: clamped first.
 template <int PL>
-__device__ __forceinline__ void store_act(half_t* p, int plane, const float* v) {
+__device__ __forceinline__ void store_act(half_t* p, int plane, const float* v, int ci = 0) {
     h8_t hi;
 #pragma unroll
     for (int i = 0; i < 8; ++i) hi[i] = sat_half(v[i]);
     *(h8_t*)p = hi;
-    if (PL >= 2) {
+    if (PL == 4) {
+        float ql[8], q8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            ql[i] = fminf(fmaxf((v[i] - (float)hi[i]) * (float)(1 << MCAMD_F8_SXL), -448.f), 448.f);
+            q8[i] = fminf(fmaxf(v[i] * (float)(1 << MCAMD_F8_SX8), -448.f), 448.f);
+        }
+        int wl[2], w8[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            wl[i] = __builtin_amdgcn_cvt_pk_fp8_f32(ql[4 * i], ql[4 * i + 1], 0, false);
+            wl[i] = __builtin_amdgcn_cvt_pk_fp8_f32(ql[4 * i + 2], ql[4 * i + 3], wl[i], true);
+            w8[i] = __builtin_amdgcn_cvt_pk_fp8_f32(q8[4 * i], q8[4 * i + 1], 0, false);
+            w8[i] = __builtin_amdgcn_cvt_pk_fp8_f32(q8[4 * i + 2], q8[4 * i + 3], w8[i], true);
+        }
+        char* b = (char*)(p - ci + plane) + ci;      // byte ci of the e4m3 region
+        typedef int i32x2_t __attribute__((ext_vector_type(2)));
+        *(i32x2_t*)b = i32x2_t{wl[0], wl[1]};
+        *(i32x2_t*)(b + plane) = i32x2_t{w8[0], w8[1]};
+    } else if (PL >= 2) {
         h8_t lo;
 #pragma unroll
         for (int i = 0; i < 8; ++i) lo[i] = (half_t)(v[i] - (float)hi[i]);   // exact difference, one rounding; |lo| <= ulp(hi)/2
         *(h8_t*)(p + plane) = lo;
         if (PL == 3) *(h8_t*)(p + 2 * plane) = hi;      // (PL == 2: the consumer wraps its third K part onto the hi plane)
     }
+}
+// dst2 may be stored in another form than dst (its consumer is another convolution): wave-uniform switch
+template <int PL>
+__device__ __forceinline__ void store_act2(int pl2, half_t* p, int plane, const float* v, int ci) {
+    if (PL < 2 || pl2 == PL) store_act<PL>(p, plane, v, ci);
+    else if (pl2 == 4) store_act<4>(p, plane, v, ci);
+    else if (pl2 == 3) store_act<3>(p, plane, v, ci);
+    else if (pl2 == 2) store_act<2>(p, plane, v, ci);
+    else store_act<1>(p, plane, v, ci);
 }
 // offset of pixel (b, h, w) from the buffer pointer; pw = 2: padded NHWC, pw = 1: shared-halo form (include/mcamd.h)
 __device__ __forceinline__ long long pad_off(int b, int h, int w, int H, int W, int ld, int pw = 2) {
@@ -195,7 +228,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(ActArgs a) {
                 float z = v[i] * sc[i] + sh[i];
                 v[i] = z > 0.f ? z : z * a.slope;
             }
-            store_act<PL>(a.dst + pad_off(b, h, w, a.H, a.W, a.dst_ld, a.dst_pw) + a.dst_choff + c8, a.dst_plane, v);
+            store_act<PL>(a.dst + pad_off(b, h, w, a.H, a.W, a.dst_ld, a.dst_pw) + a.dst_choff + c8, a.dst_plane, v, a.dst_choff + c8);
         } else {
             int b = (int)(pix / (Ho * Wo));
             int rem = (int)(pix - (long long)b * Ho * Wo);
@@ -217,17 +250,17 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(ActArgs a) {
                     float z = act[k][i] * sc[i] + sh[i];
                     act[k][i] = z > 0.f ? z : z * a.slope;
                 }
-                if (a.dst2) store_act<PL>(a.dst2 + pad_off(b, h, w, a.H, a.W, a.dst2_ld, a.dst2_pw) + a.dst2_choff + c8, a.dst2_plane, act[k]);
+                if (a.dst2) store_act2<PL>(a.dst2_pl, a.dst2 + pad_off(b, h, w, a.H, a.W, a.dst2_ld, a.dst2_pw) + a.dst2_choff + c8, a.dst2_plane, act[k], a.dst2_choff + c8);
             }
             long long dp = pad_off(b, ho, wo, Ho, Wo, a.dst_ld, a.dst_pw) + a.dst_choff;
             if (MODE == MCAMD_DST_POOL) {
                 float m[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) m[i] = fmaxf(fmaxf(act[0][i], act[1][i]), fmaxf(act[2][i], act[3][i]));
-                store_act<PL>(a.dst + dp + c8, a.dst_plane, m);
+                store_act<PL>(a.dst + dp + c8, a.dst_plane, m, a.dst_choff + c8);
             } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) store_act<PL>(a.dst + dp + k * a.C + c8, a.dst_plane, act[k]);
+                for (int k = 0; k < 4; ++k) store_act<PL>(a.dst + dp + k * a.C + c8, a.dst_plane, act[k], a.dst_choff + k * a.C + c8);
             }
         }
     }
@@ -869,17 +902,22 @@ extern "C" int mcamd_bn_act_fwd(const mcamd_act_desc* d, void* stream) {
     MCAMD_REQUIRE(d->mode != MCAMD_DST_PLAIN || !d->dst2, "bn_act_fwd: dst2 only with pool/reorg");
     MCAMD_REQUIRE(d->y_dtype == 0 || d->y_dtype == 1, "bn_act_fwd: y_dtype %d (0 = fp16, 1 = fp32)", d->y_dtype);
     const int planes = d->planes == 0 ? 1 : d->planes;
-    MCAMD_REQUIRE(planes >= 1 && planes <= 3, "bn_act_fwd: planes must be 1, 2 or 3 (got %d)", d->planes);
+    const int planes2 = d->planes2 == 0 ? planes : d->planes2;
+    MCAMD_REQUIRE(planes >= 1 && planes <= 4 && planes2 >= 1 && planes2 <= 4 && (planes == 1) == (planes2 == 1),
+                  "bn_act_fwd: planes / planes2 must be 1, or both of 2, 3, 4 (got %d, %d)", d->planes, d->planes2);
     if (planes >= 2) {
         const int span = d->mode == MCAMD_DST_REORG ? 4 * d->C : d->C;
-        MCAMD_REQUIRE(d->dst_plane % 8 == 0 && d->dst_plane >= span && d->dst_choff + (planes - 1) * d->dst_plane + span <= d->dst_ld,
+        // (4: the e4m3 region is one plane stride of fp16 units, like a lo plane)
+        MCAMD_REQUIRE(d->dst_plane % 8 == 0 && d->dst_plane >= span &&
+                          d->dst_choff + (planes == 4 ? 2 * d->dst_plane : (planes - 1) * d->dst_plane + span) <= d->dst_ld,
                       "bn_act_fwd: %d planes of stride %d (+ offset %d, %d channels) do not fit dst_ld %d", planes, d->dst_plane,
                       d->dst_choff, span, d->dst_ld);
         MCAMD_REQUIRE(!d->dst2 || (d->dst2_plane % 8 == 0 && d->dst2_plane >= d->C &&
-                                   d->dst2_choff + (planes - 1) * d->dst2_plane + d->C <= d->dst2_ld),
-                      "bn_act_fwd: %d planes of stride %d do not fit dst2_ld %d", planes, d->dst2_plane, d->dst2_ld);
+                                   d->dst2_choff + (planes2 == 4 ? 2 * d->dst2_plane : (planes2 - 1) * d->dst2_plane + d->C) <= d->dst2_ld),
+                      "bn_act_fwd: %d planes of stride %d do not fit dst2_ld %d", planes2, d->dst2_plane, d->dst2_ld);
     }
     ActArgs a;
+    a.dst2_pl = planes2;
     a.dst_plane = d->dst_plane, a.dst2_plane = d->dst2_plane;
     MCAMD_REQUIRE((d->dst_pad == 0 || d->dst_pad == 1) && (d->dst2_pad == 0 || d->dst2_pad == 1), "bn_act_fwd: dst_pad / dst2_pad must be 0 or 1");
     a.dst_pw = d->dst_pad ? 1 : 2, a.dst2_pw = d->dst2_pad ? 1 : 2;
@@ -901,9 +939,11 @@ extern "C" int mcamd_bn_act_fwd(const mcamd_act_desc* d, void* stream) {
     const int CH = d->C / 8;
     const bool fixed = CH <= 256 && 256 % CH == 0;
     const bool y32 = d->y_dtype == 1;
+    MCAMD_REQUIRE(planes != 4 || y32, "bn_act_fwd: planes 4 (e4m3 corrections) goes with an fp32 y");
 #define ACT_INST(MODE_, FIXED_)                                                                                         \
     do {                                                                                                                \
-        if (y32 && planes == 3) hipLaunchKernelGGL((bn_act_fwd_kernel<MODE_, FIXED_, true, 3>), dim3(grid), dim3(256), 0, st, a);       \
+        if (y32 && planes == 4) hipLaunchKernelGGL((bn_act_fwd_kernel<MODE_, FIXED_, true, 4>), dim3(grid), dim3(256), 0, st, a);       \
+        else if (y32 && planes == 3) hipLaunchKernelGGL((bn_act_fwd_kernel<MODE_, FIXED_, true, 3>), dim3(grid), dim3(256), 0, st, a);  \
         else if (y32 && planes == 2) hipLaunchKernelGGL((bn_act_fwd_kernel<MODE_, FIXED_, true, 2>), dim3(grid), dim3(256), 0, st, a);  \
         else if (y32) hipLaunchKernelGGL((bn_act_fwd_kernel<MODE_, FIXED_, true, 1>), dim3(grid), dim3(256), 0, st, a);                 \
         else if (planes == 3) hipLaunchKernelGGL((bn_act_fwd_kernel<MODE_, FIXED_, false, 3>), dim3(grid), dim3(256), 0, st, a);        \

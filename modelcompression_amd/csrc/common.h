@@ -90,3 +90,14 @@ __device__ __forceinline__ int swz(int row) {
     return CPR == 4 ? ((row >> 2) & 3) : ((row >> 1) & 7);
 }
 
+// Scales of the fp8 correction operands (mcamd_conv_geom.x_f8, mcamd_act_desc.planes == 4, mcamd_pack_job.split == 2):
+//   lo8 = e4m3(x_lo * 2^F8_SXL),  x8 = e4m3(x * 2^F8_SX8),  w8 = e4m3(w_hi * 2^F8_SW8),  wlo8 = e4m3(w_lo * 2^F8_SWL)
+// lo8 * w8 and x8 * wlo8 carry the same factor 2^F8_SUM, which the block-scaled MFMA takes back through its e8m0 scale
+// operands.  Ranges: |x| <= 224 and |w| <= 14 before the e4m3 maximum 448 clamps (the correction of such an entry is then
+// partly lost: never worse than plain fp16 operands); three mantissa bits down to |x| 2^-7 (x8), 2^-7 (lo8) and |w| 2^-11.
+#define MCAMD_F8_SXL 12
+#define MCAMD_F8_SX8 1
+#define MCAMD_F8_SW8 5
+#define MCAMD_F8_SWL 16
+#define MCAMD_F8_SUM 17
+static_assert(MCAMD_F8_SXL + MCAMD_F8_SW8 == MCAMD_F8_SUM && MCAMD_F8_SX8 + MCAMD_F8_SWL == MCAMD_F8_SUM, "one scale for both correction terms");

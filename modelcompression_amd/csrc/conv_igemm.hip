@@ -444,6 +444,12 @@ void mcamd_igemm_tile(long long M, int n, int cin_tap, int ktot, int out[4], boo
     out[0] = t.bm, out[1] = t.bn, out[2] = t.bk, out[3] = t.kind;
 }
 
+// x_f8 geometry (cin_tap = 2 P, ktot = ntaps * 2 P): the three-product problem of the same layer takes the ping-pong tile
+bool mcamd_igemm_f8_ok(long long M, int n, int cin_tap, int ktot) {
+    if (cin_tap % 128 != 0) return false;       // P % 64 == 0: whole 64-channel K blocks on either side of the fp16 / fp8 boundary
+    return pick_tile(M, n, cin_tap / 2 * 3, ktot / 2 * 3, false, false).kind == 2;
+}
+
 static int igemm_mtiles(long long M, int bm) { return (int)((M + bm - 1) / bm); }
 
 // Number of persistent workgroups along M (== rows of the BN-statistics slab).
@@ -482,7 +488,15 @@ static void launch_one(const IgemmArgs& a, int rows, int ntiles, hipStream_t st)
 int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st) {
     if (mcamd_win3x3_ok(a)) return mcamd_win3x3_launch(a, st);   // conv2 dgrad: rolling LDS window (conv_win.hip)
     const bool conc = a.concurrent != 0;
-    TileCfg t = pick_tile(a.M, a.N, a.cin_tap, a.ktot, a.mode == MCAMD_EPI_RAW_F16, conc);   // stats slabs only exist with RAW
+    const bool f8 = a.f8_from != 0x7fffffff;
+    // (the fp8 correction form, mcamd_conv_geom.x_f8: K is 2/3 of the three-product problem's; the tile is chosen for that
+    // problem, so that a layer takes the same tile -- and the same statistics slab -- in either form)
+    const int ktile = f8 ? a.ktot / 2 * 3 : a.ktot;
+    TileCfg t = pick_tile(a.M, a.N, f8 ? a.cin_tap / 2 * 3 : a.cin_tap, ktile, a.mode == MCAMD_EPI_RAW_F16, conc);   // stats slabs only exist with RAW
+    if (f8 && t.kind != 2) {
+        mcamd_set_error("igemm: no fp8-correction kernel for M %d N %d K %d (mcamd_conv_fwd_f8_ok)", a.M, a.N, a.ktot);
+        return MCAMD_EINVAL;
+    }
     if (t.kind == 4) return mcamd_small3x3_launch(a, st);
     if (a.cin_tap % t.bk != 0 || a.ktot % t.bk != 0) {
         mcamd_set_error("igemm: K per tap (%d) must be a multiple of %d", a.cin_tap, t.bk);
@@ -490,7 +504,7 @@ int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st) {
     }
     int ntiles = (a.N + t.bn - 1) / t.bn;
     a.num_mtiles = igemm_mtiles(a.M, t.bm);
-    int rows = mcamd_igemm_rows(a.M, a.N, a.cin_tap, a.ktot, a.mode == MCAMD_EPI_RAW_F16, conc);
+    int rows = mcamd_igemm_rows(a.M, a.N, f8 ? a.cin_tap / 2 * 3 : a.cin_tap, ktile, a.mode == MCAMD_EPI_RAW_F16, conc);
     a.num_pslots = rows;
     a.num_ntiles = ntiles;
     a.xcd_order = 1;

@@ -33,6 +33,19 @@
 // The accumulation order over K equals igemm_kernel's, so raw outputs are bit-identical to it
 // (tests/test_kernels_gpu.py::test_pingpong_*).
 //
+// F8 (round 4, the split-operand forward of the default precision): the K loop's tail is the fp8 CORRECTION part of
+// the product.  x*w = x_hi*w_hi + (x_lo*w_hi + x_hi*w_lo) + O(2^-22): the bracket is 2^-11 of the result, so its operands
+// need 3-4 bits, not 11 -- e4m3 copies [lo8 | x8] of the activation and [w8 | wlo8] of the weights (kernels.h: scales),
+// multiplied by v_mfma_scale_f32_32x32x64_f8f6f4 INTO THE SAME ACCUMULATORS (the C/D layout is shape-determined), whose
+// e8m0 scale operands take the 2^17 back.  A 64-byte LDS row that holds 32 fp16 k's of an fp16 chunk holds 64 e4m3 k's
+// of an fp8 chunk; the concatenation of the two k16-step fragments a lane reads from it (bytes [16h, 16h+16) and
+// [32+16h, 32+16h+16) of row r) is a valid 32-byte operand of the 64-k instruction because A and B are gathered the same way
+// (any k permutation common to both sums the same products; tools/f8_probe.hip).  DMA, swizzle, ring, barriers and the
+// fragment reads are byte-identical to the fp16 chunks: only the matrix phase differs -- ONE 32x32x64 fp8 MFMA per block
+// instead of two 32x32x16 fp16 ones, the same cycles for twice the k's.  Three products cost 2 instead of 3 units of
+// MFMA time and of staged bytes.  Residual: the bracket's relative error 2^-4 / sqrt(3) per operand, ~5 % of what plain
+// fp16 operands lose.
+//
 // Operand addressing, LDS swizzle (on the DMA source), persistent M tiles per N tile, BatchNorm partial
 // sums and the epilogues are those of conv_igemm.hip.  Replaces F.conv2d at reference
 // src/pruning/weightPruning/layers.py:60-64 and its autograd input gradient.
@@ -75,6 +88,21 @@ template <> struct Shape<16> {
     }
 };
 
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+// F8 kernels keep the two k16-step fragments of a 64-byte row as ONE 8-register value from the moment they are read: it is
+// the 32-byte operand of the 64-k fp8 instruction as it stands, and its halves are the operands of the fp16 instruction
+// (built at the use instead -- concatenating two h8_t values in the matrix phase -- hipcc copies every fragment: +56
+// registers and spills)
+__device__ __forceinline__ i32x8_t read_pair(const char* p0, const char* p1) {
+    const i32x4_t lo = *(const i32x4_t*)p0, hi = *(const i32x4_t*)p1;
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ h8_t half_of(i32x8_t v, int s) {
+    const i32x4_t q = s ? __builtin_shufflevector(v, v, 4, 5, 6, 7) : __builtin_shufflevector(v, v, 0, 1, 2, 3);
+    return __builtin_bit_cast(h8_t, q);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -87,8 +115,9 @@ __device__ __forceinline__ void wait_vm() {
 // one, so the counted waits differ per group.
 // BN = 256 or 128 columns (128: the layers with 128 output channels and the dgrads whose 256-column tiles
 // would be too few; staged bytes per flop are 1.3x those of 256 columns, still 0.75x those of 128x128).
-template <int EPI, int BM, int BN, int MS>
+template <int EPI, int BM, int BN, int MS, bool F8 = false>
 __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
+    static_assert(!F8 || MS == 32, "the fp8 correction chunks are 32x32x64 blocks");
     typedef Shape<MS> SH;
     typedef typename SH::acc_t acc_v;
     constexpr int AR = SH::AR, KS = SH::KS;
@@ -217,7 +246,12 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
         __builtin_amdgcn_s_barrier();
         if (group == 1) __builtin_amdgcn_s_barrier();   // the stagger: group 1 runs one episode behind
 
-        for (int p = 0; p < nchunks; ++p) {
+        // one chunk = one memory phase + one matrix phase; IS8: a chunk of the fp8 correction part (F8 kernels run two loops,
+        // fp16 chunks then fp8 chunks: with one loop and a branch around the two kinds of matrix phase hipcc kept two
+        // register sets for the accumulators and copied between them)
+        // (IS8 is a literal at both call sites and the lambda is inlined: the branch folds.  A generic lambda with a tag type
+        // made hipcc drop the kernels' host stubs.)
+        auto chunk_phases = [&](const int p, const bool IS8) __attribute__((always_inline)) {
             // ---------------- memory phase: wait for chunk p+1, read the fragments of chunk p ----------------
             __builtin_amdgcn_sched_barrier(0);   // nothing of this phase is scheduled above the barrier that opens it
             const bool more = p + NST - 1 < nchunks;
@@ -235,16 +269,24 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
             // chunk p+1 must have landed; chunk p+2 (issued in matrix phase p-1) may still be in flight
             wait_chunks(p + 2 < nchunks ? 1 : 0);
             const char* sbase = smem + (p & (NST - 1)) * STAGE_BYTES;
-            h8_t af[KS][TM], bf[KS][TN];
+            h8_t af[F8 ? 1 : KS][F8 ? 1 : TM], bf[F8 ? 1 : KS][F8 ? 1 : TN];
+            i32x8_t af8[F8 ? TM : 1], bf8[F8 ? TN : 1];
+            if constexpr (F8) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                bf[0][j] = *(const h8_t*)(sbase + b_off0 + j * (MS * CPR * 16));
-                if (KS == 2) bf[KS - 1][j] = *(const h8_t*)(sbase + b_off1 + j * (MS * CPR * 16));
-            }
+                for (int j = 0; j < TN; ++j) bf8[j] = read_pair(sbase + b_off0 + j * (MS * CPR * 16), sbase + b_off1 + j * (MS * CPR * 16));
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                af[0][i] = *(const h8_t*)(sbase + a_off0 + i * (MS * CPR * 16));
-                if (KS == 2) af[KS - 1][i] = *(const h8_t*)(sbase + a_off1 + i * (MS * CPR * 16));
+                for (int i = 0; i < TM; ++i) af8[i] = read_pair(sbase + a_off0 + i * (MS * CPR * 16), sbase + a_off1 + i * (MS * CPR * 16));
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bf[0][j] = *(const h8_t*)(sbase + b_off0 + j * (MS * CPR * 16));
+                    if (KS == 2) bf[KS - 1][j] = *(const h8_t*)(sbase + b_off1 + j * (MS * CPR * 16));
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    af[0][i] = *(const h8_t*)(sbase + a_off0 + i * (MS * CPR * 16));
+                    if (KS == 2) af[KS - 1][i] = *(const h8_t*)(sbase + a_off1 + i * (MS * CPR * 16));
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired BEFORE the barrier (WAR rule above)
             __builtin_amdgcn_sched_barrier(0);
@@ -254,17 +296,50 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
             // (issued here, not in a burst at the start of the memory phase: every wave feeds the DMA path all the
             // time and the issue cost hides behind this wave's own MFMAs)
             __builtin_amdgcn_s_setprio(1);
+            bool did8 = false;
+            if constexpr (F8) {
+                if (IS8) {                 // fp8 correction chunk: one 64-k MFMA per block
+                    did8 = true;
+                    // e8m0 scales 1 and 2^-17 (a VGPR of four scale bytes each; op_sel picks byte 0).  Inline assembly: through
+                    // the builtin hipcc does not accumulate in place (no tied form of the scaled instruction: every block got a
+                    // second set of 16 registers and 16 v_mov back -- 256 registers + 254 spilled for the 256 x 256 tile).
+                    // Hazards the assembler does not see: none inside the loop (the blocks are independent, the operands come
+                    // from LDS reads retired before the barrier, the next reader of an accumulator is an MFMA two barriers
+                    // later); the epilogue's VALU reads are padded after the loop.
+                    const int SA = 127 * 0x01010101, SB = (127 - MCAMD_F8_SUM) * 0x01010101;
 #pragma unroll
-            for (int s = 0; s < KS; ++s)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                        for (int j = 0; j < TN; ++j) {
+                            asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"
+                                         : "+v"(acc[i][j])
+                                         : "v"(af8[i]), "v"(bf8[j]), "v"(SA), "v"(SB));
+                            const int m = i * TN + j;                       // the 4 DMA instructions spread over the TM * TN MFMAs
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = SH::mfma(af[s][i], bf[s][j], acc[i][j]);
-                        const int m = (s * TM + i) * TN + j;            // 0 .. KS*TM*TN-1
-                        constexpr int EVERY = KS * TM * TN / 4;         // one DMA instruction per EVERY MFMAs (at most 4)
-                        if (more && m % EVERY == 1) issue_piece(m / EVERY);
-                    }
+                            for (int q = 0; q < 4; ++q)
+                                if (more && q * (TM * TN) / 4 == m) issue_piece(q);
+                        }
+                }
+            }
+            if (!did8) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            if constexpr (F8) acc[i][j] = SH::mfma(half_of(af8[i], s), half_of(bf8[j], s), acc[i][j]);
+                            else acc[i][j] = SH::mfma(af[s][i], bf[s][j], acc[i][j]);
+                            const int m = (s * TM + i) * TN + j;            // 0 .. NM-1
+                            // the 4 DMA instructions spread over the NM MFMAs, the first one behind the second MFMA
+                            // (NM = 6, the 192 x 128 tile on 32 x 32 blocks: one per MFMA from the first -- `m % (NM / 4) == 1`
+                            // never fired there and the ring was never refilled; found with the fp8 form, round 4)
+                            constexpr int NM = KS * TM * TN;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (more && q * NM / 4 + (NM >= 8 ? 1 : 0) == m) issue_piece(q);
+                        }
+            }
             __builtin_amdgcn_s_setprio(0);
             if (more) {
                 ++st_q;
@@ -279,8 +354,16 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
+        };
+        {
+            const int p8 = F8 ? (a.f8_from < nchunks ? a.f8_from : nchunks) : nchunks;
+            int p = 0;
+            for (; p < p8; ++p) chunk_phases(p, false);
+            if constexpr (F8)
+                for (; p < nchunks; ++p) chunk_phases(p, true);
         }
         if (group == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last barrier: both groups aligned again
+        if constexpr (F8) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // last (assembly) MFMA -> VALU reads of the accumulators
 
         // ------------------------------- epilogue (as conv_igemm.hip) -------------------------------
         if constexpr (EPI == MCAMD_EPI_NCHW_F32) {
@@ -418,12 +501,12 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
     }
 }
 
-template <int EPI, int BM, int BN, int MS>
+template <int EPI, int BM, int BN, int MS, bool F8 = false>
 static void launch_pp(const IgemmArgs& a, int rows, int ntiles, hipStream_t st) {
     constexpr size_t ring = (size_t)NST * (BM + BN) * CPR * 16;   // <= 128 KB: the ring, then the fp16 output tile
     static_assert((size_t)BM * BN * 2 <= ring, "output tile fits the ring");
-    MCAMD_LDS_OPT_IN((igemm_pp_kernel<EPI, BM, BN, MS>), ring);
-    hipLaunchKernelGGL((igemm_pp_kernel<EPI, BM, BN, MS>), dim3(round_up_int(rows, 8) * ntiles + 8), dim3(NT), ring, st, a);
+    MCAMD_LDS_OPT_IN((igemm_pp_kernel<EPI, BM, BN, MS, F8>), ring);
+    hipLaunchKernelGGL((igemm_pp_kernel<EPI, BM, BN, MS, F8>), dim3(round_up_int(rows, 8) * ntiles + 8), dim3(NT), ring, st, a);
 }
 
 // a.* filled as for mcamd_igemm_launch; the packed weights are padded to 256 rows, cin_tap % 32 == 0, at least one
@@ -432,6 +515,18 @@ int mcamd_igemm_pp_launch(const IgemmArgs& a, int bm, int bn, int rows, int ntil
     if (a.cin_tap % BK != 0 || a.ktot < BK || a.kb % BK != 0 || (bm != 256 && bm != 192) || (bn != 256 && bn != 128)) {
         mcamd_set_error("igemm_pp: K per tap (%d) must be a multiple of %d, tile (%d x %d) 256|192 x 256|128", a.cin_tap, BK, bm, bn);
         return MCAMD_EINVAL;
+    }
+    if (a.f8_from != 0x7fffffff) {       // fp8 correction part (mcamd_conv_geom.x_f8): fp32 output with BatchNorm sums only
+        if (a.mode != MCAMD_EPI_RAW_F32 || a.f8_from <= 0 || a.f8_from >= a.ktot / BK || a.wrap != 0x7fffffff) {
+            mcamd_set_error("igemm_pp: the fp8 correction form needs epilogue mode 3, no x_wrap and 0 < f8_from (%d) < chunks", a.f8_from);
+            return MCAMD_EINVAL;
+        }
+        if (bm == 256 && bn == 256) launch_pp<MCAMD_EPI_RAW_F32, 256, 256, 32, true>(a, rows, ntiles, st);
+        else if (bm == 192 && bn == 256) launch_pp<MCAMD_EPI_RAW_F32, 192, 256, 32, true>(a, rows, ntiles, st);
+        else if (bm == 256) launch_pp<MCAMD_EPI_RAW_F32, 256, 128, 32, true>(a, rows, ntiles, st);
+        else launch_pp<MCAMD_EPI_RAW_F32, 192, 128, 32, true>(a, rows, ntiles, st);
+        MCAMD_LAUNCH_CHECK("igemm_pp(f8)");
+        return MCAMD_OK;
     }
     const int ms = MCAMD_ENV_INT("MCAMD_PP_MFMA", 16) == 32 ? 32 : 16;
 #define PP_SHAPE(EPI_, BM_, BN_)                                           \

@@ -36,7 +36,9 @@ struct IgemmArgs {
     int y2_ld, y2_choff;
     int concurrent;  // mcamd_conv_epilogue.concurrent (dgrad): tiles chosen for CU-time, see pick_tile
     int wrap;        // mcamd_conv_geom.x_wrap (INT_MAX = none): channel blocks >= wrap are read `wrap` channels lower
+    int f8_from;     // mcamd_conv_geom.x_f8: first K chunk (of 32 fp16 = 64 e4m3 values) of the fp8 correction part; INT_MAX = none
 };
+
 
 struct StemArgs {        // conv_stem.hip: forward of the 3-channel first layer
     const half_t* x;     // padded NHWC4 image
@@ -74,6 +76,7 @@ struct WgradPlan {
 
 void mcamd_igemm_tile(long long M, int n, int cin_tap, int ktot, int out[4], bool concurrent = false);   // {BM, BN, BK, kind}: kind 0 igemm_kernel, 2 igemm_pp_kernel
 int mcamd_igemm_pp_launch(const IgemmArgs& a, int bm, int bn, int rows, int ntiles, hipStream_t st);
+bool mcamd_igemm_f8_ok(long long M, int n, int cin_tap, int ktot);   // the fp8-correction form exists for the tile this shape takes
 int mcamd_igemm_rows(long long M, int n, int cin_tap, int ktot, bool raw_epilogue = true, bool concurrent = false);
 int mcamd_igemm_launch(IgemmArgs& a, hipStream_t st);
 

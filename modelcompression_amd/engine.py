@@ -160,6 +160,9 @@ class Engine:
         self._logits = self._gout = self._flat = None
         self._pack_on_side = False
         self.fold_dead = os.environ.get("MCAMD_FOLD_DEAD", "1") == "1"
+        # "mixed": the two correction products of the split-operand forward from e4m3 copies on the block-scaled fp8 MFMAs
+        # (csrc/conv_igemm_pp.hip, F8).  "fp16x3" keeps all three products on fp16 operands: it is the tests' tight reference.
+        self.f8 = precision == "mixed" and os.environ.get("MCAMD_F8", "1") == "1"
         self.bn_narrow_on = True      # BatchNorm / activation passes of a folded producer on its kept channels only
         self.bwd_from_act = True      # split-operand engines: BatchNorm backward of PLAIN blocks from the stored activation
         self._side_stream = None
@@ -415,11 +418,16 @@ class Engine:
             return l.li == 0
         for lay in self.layers:
             g = lay.geom
-            # forward geometry: the K-concatenated problem [x_hi | x_lo | x_hi] x [w_hi | w_hi | w_lo]
+            # forward geometry: the K-concatenated problem [x_hi | x_lo | x_hi] x [w_hi | w_hi | w_lo] (the packed buffer is
+            # sized for it), or its fp8-correction form where the layer's kernel has one (_set_geom_f)
             wrap = 2 * lay.tin.ps if (self.act_planes == 2 and lay.li > 0) else 0      # (the network input keeps three planes)
             lay.geom_f = g if lay.level == 1 else ops.geom(B, lay.H, lay.W, lay.k, lay.level * lay.cin, lay.cout,
                                                            lay.tin.ld, 0, 0, lay.pad, wrap)
             nf, _ = ops.packed_elems(lay.geom_f)
+            lay.f8 = False
+            if self.precise:
+                lay.n_act, lay.geom_act = lay.cout, g
+                self._set_geom_f(lay)
             _, nd = ops.packed_elems(g)
             # zero-initialised: the one-launch packer writes real entries only (pad rows / channels stay zero)
             lay.wp = torch.zeros(nf, dtype=ops.HALF, device=dev)
@@ -617,12 +625,13 @@ class Engine:
                 if lay.stem:
                     continue
                 self._pack_keep += [w, mask]
+                split = 2 if lay.f8 else (1 if lay.level == 3 else 0)      # mcamd_pack_job.split
                 if lay.fold is not None:     # augmented weights (kept inputs + the folded ones-channel), rebuilt per step
                     jobs.append(dict(w=lay.waug, mask=None, rows=None, cols=None, cout=lay.n_act, cin=lay.fold_aug,
-                                     ksize=lay.k, dst_fwd=lay.wp, dst_dgrad=lay.wd, split=lay.level == 3))
+                                     ksize=lay.k, dst_fwd=lay.wp, dst_dgrad=lay.wd, split=split))
                     continue
                 jobs.append(dict(w=w, mask=mask, rows=lay.g_rows, cols=lay.g_cols, cout=lay.n_act, cin=lay.cin, ksize=lay.k,
-                                 dst_fwd=lay.wp, dst_dgrad=lay.wd, split=lay.level == 3))
+                                 dst_fwd=lay.wp, dst_dgrad=lay.wd, split=split))
             self._pack_table = ops.pack_table(jobs, self.device) if jobs else None
             self._pack_key = tkey
         for lay in self.layers:
@@ -683,6 +692,22 @@ class Engine:
             return
         wrap = 2 * lay.tin.ps if (self.act_planes == 2 and lay.li > 0) else 0      # (the network input keeps three planes)
         lay.geom_f = ops.geom(self.B, lay.H, lay.W, lay.k, lay.level * cin_eff, lay.n_act, lay.tin.ld, 0, 0, lay.pad, wrap)
+        # fp8 correction terms (mcamd_conv_geom.x_f8, "mixed" only): x_hi w_hi on the fp16 MFMAs, x_lo w_hi + x_hi w_lo from
+        # e4m3 copies on the block-scaled fp8 MFMAs -- where the layer's forward takes the ping-pong kernel and its input is
+        # written by an ordinary block's activation pass (which then stores hi | [lo8 | x8], _planes_for)
+        lay.f8 = False
+        prod = self.producer_of.get(lay.src)
+        if (self.f8 and wrap and prod is not None and not lay.stem and not prod.stem and lay.li >= int(os.environ.get("MCAMD_DBG_F8_MIN_LI", "0"))
+                and lay.bn is not None and cin_eff % 64 == 0 and lay.tin.ps == cin_eff and lay.tin.choff == 0):
+            g8 = ops.geom(self.B, lay.H, lay.W, lay.k, 2 * cin_eff, lay.n_act, lay.tin.ld, 0, 0, lay.pad, 0, x_f8=cin_eff)
+            if ops.conv_fwd_f8_ok(g8):
+                lay.f8, lay.geom_f = True, g8
+
+    def _planes_for(self, tid):
+        """Storage form of activation tensor `tid` in a split-operand engine (mcamd_act_desc.planes): 4 = hi | e4m3
+        corrections when its consumer multiplies fp8 correction terms, else hi | lo (or hi | lo | hi)."""
+        c = self.consumer_of.get(tid)
+        return 4 if (c is not None and c.f8) else self.act_planes
 
     def _update_compaction(self):
         """Sparse-masked path: skip the filters a filter mask removed (north_star: "a sparse-masked wgrad
@@ -861,6 +886,14 @@ class Engine:
                 rows = ops.stats_rows(lay.geom_f, L.EPI_RAW_F32) if self.precise else ops.stats_rows(lay.geom_act)
                 if lay.stats.shape[0] != rows:
                     lay.stats = torch.zeros(rows, 2, lay.stats.shape[2], dtype=torch.float32, device=dev)
+        for prod in self.layers:         # a ones-channel written once (exact narrowed pass) in front of an fp8-correction
+            if prod.ones_idx < 0 or not prod.bn_width or prod.bn_width != prod.n_act:     # consumer: its x8 byte = e4m3(1 * 2)
+                continue
+            for tid, t in ((prod.out_id, prod.out_t), (prod.out2_id, prod.out2_t)):
+                if t is not None and self._planes_for(tid) == 4:
+                    v8 = ops.padded_view(self.bufs[t.buf].view(torch.uint8), self.B, t.H, t.W, 2 * t.ld,
+                                         pad=ops.pad_of(self.bufs[t.buf]))[:, 1:-1, 1:-1]
+                    v8[..., 2 * t.choff + 3 * t.ps + prod.n_act] = 0x40
         return wbytes
 
     def _fold_constants(self, prod, training):
@@ -1002,8 +1035,9 @@ class Engine:
                                lay.slope, lay.mode, self.bufs[t.buf], t.ld, t.choff,
                                self.bufs[t2.buf] if t2 is not None else None,
                                t2.ld if t2 is not None else 0, t2.choff if t2 is not None else 0, border=lay.border,
-                               planes=self.act_planes, dst_plane=t.ps, dst2_plane=t2.ps if t2 is not None else 0,
-                               dst_pad=self._pad_for(t.W), dst2_pad=self._pad_for(t2.W) if t2 is not None else 0)
+                               planes=self._planes_for(lay.out_id), dst_plane=t.ps, dst2_plane=t2.ps if t2 is not None else 0,
+                               dst_pad=self._pad_for(t.W), dst2_pad=self._pad_for(t2.W) if t2 is not None else 0,
+                               planes2=self._planes_for(lay.out2_id) if t2 is not None else 0)
                 continue
             if (not training and self.fuse_eval and lay.perm is None and lay.border is None
                     and (lay.out2_t is None or lay.mode == L.DST_POOL)

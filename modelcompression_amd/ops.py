@@ -78,8 +78,13 @@ def padded_view(buf, B, H, W, ld, pad=None):
     return buf[: B * (H + 2) * (W + 2) * ld].view(B, H + 2, W + 2, ld)
 
 
-def geom(B, H, W, ksize, cin, cout, x_ld, x_choff=0, stem=0, pad=0, x_wrap=0):
-    return ConvGeom(B, H, W, ksize, cin, cout, x_ld, x_choff, stem, pad, x_wrap)
+def geom(B, H, W, ksize, cin, cout, x_ld, x_choff=0, stem=0, pad=0, x_wrap=0, x_f8=0):
+    return ConvGeom(B, H, W, ksize, cin, cout, x_ld, x_choff, stem, pad, x_wrap, x_f8)
+
+
+def conv_fwd_f8_ok(g):
+    """Does mcamd_conv_fwd accept this geometry with fp8 correction terms (mcamd_conv_geom.x_f8)?"""
+    return bool(L.lib().mcamd_conv_fwd_f8_ok(C.byref(g)))
 
 
 def packed_elems(g):
@@ -129,7 +134,7 @@ def pack_table(jobs, device):
         for name in ("mask", "dst_fwd", "dst_dgrad", "rows", "cols"):
             setattr(a, name, j[name].data_ptr() if j.get(name) is not None else None)
         a.first_tile, a.cout, a.cin, a.ksize = total, j["cout"], j["cin"], j["ksize"]
-        a.split = 1 if j.get("split") else 0
+        a.split = int(j.get("split") or 0)      # 0 plain, 1 [w_hi | w_hi | w_lo], 2 [w_hi | w8 | wlo8] (mcamd_pack_job.split)
         total += ((j["cout"] + 31) // 32) * ((j["cin"] + 31) // 32)
     host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
     return host.to(device), len(jobs), total
@@ -299,13 +304,13 @@ def unfold_wgrad(w, mask, rows, cols, beta, slope, n, cin_k, dwaug, dw, prod_dbe
 
 
 def bn_act_fwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, slope, mode, dst, dst_ld, dst_choff=0, dst2=None,
-               dst2_ld=0, dst2_choff=0, border=None, planes=1, dst_plane=0, dst2_plane=0, dst_pad=0, dst2_pad=0):
+               dst2_ld=0, dst2_choff=0, border=None, planes=1, dst_plane=0, dst2_plane=0, dst_pad=0, dst2_pad=0, planes2=0):
     """`border`: optional fp32 [16, C] table added to the raw conv output by border class (slim models).
     `y` may be fp16 or fp32 (conv_fwd_raw / conv_fwd_raw32).  planes=3: split (hi | lo | hi) activation storage of
     the "fp16x3" precision mode with plane strides dst_plane / dst2_plane (include/mcamd.h, mcamd_act_desc.planes)."""
     d = ActDesc()
     d.y_dtype = 1 if y.dtype == torch.float32 else 0
-    d.planes, d.dst_plane, d.dst2_plane = planes, dst_plane, dst2_plane
+    d.planes, d.dst_plane, d.dst2_plane, d.planes2 = planes, dst_plane, dst2_plane, planes2
     d.dst_pad, d.dst2_pad = dst_pad, dst2_pad
     d.B, d.H, d.W, d.C = B, H, W, C_
     d.y, d.y_ld, d.y_choff = y.data_ptr(), y_ld, y_choff

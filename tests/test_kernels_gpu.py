@@ -413,6 +413,85 @@ def test_split_forward_two_planes_equals_three(dev, B, H, W, C_, cout, k):
         ops.conv_fwd_raw32(ops.geom(B, H, W, k, 3 * C_, cout, ld2, x_wrap=2 * C_ - 16), x2, wp, outs[0][0], cout, 0, None)
 
 
+def _e4m3(v, scale):
+    """OCP e4m3 (round to nearest even, clamped at +-448 like the kernels do) of v * 2^scale, decoded back to float64."""
+    q = (v.double() * 2.0 ** scale).clamp(-448.0, 448.0).float().to(torch.float8_e4m3fn)
+    return q, q.to(torch.float64)
+
+
+@pytest.mark.parametrize("B,H,W,C_,cout,k,tile", [(64, 13, 13, 128, 1024, 3, (192, 256)), (64, 52, 52, 128, 256, 3, (256, 256)),
+                                                  (16, 104, 104, 64, 128, 3, (256, 128)), (64, 13, 13, 1024, 512, 1, (192, 128))])
+def test_f8_correction_forward(dev, B, H, W, C_, cout, k, tile):
+    """mcamd_conv_geom.x_f8 (round 4): y = x_hi w_hi on the fp16 MFMAs + 2^-17 (lo8 w8 + x8 wlo8) on the block-scaled fp8
+    MFMAs, in the four ping-pong tiles.  Operands are made by the production kernels: the activation pass with
+    mcamd_act_desc.planes = 4 (hi | [lo8 | x8], checked byte for byte against torch's float8_e4m3fn) and the one-launch
+    packer with split = 2.  The fp32 output and the BatchNorm sums are held to float64 arithmetic on the SAME operands
+    (2e-6: the kernel adds exactly these products), and to the unrounded fp32 convolution the reference computes
+    (F.conv2d, layers.py:60-64) within 1.5e-5 -- plain fp16 operands are at 1.6e-4, the all-fp16 three-product form at 2e-6."""
+    gen = torch.Generator().manual_seed(C_ + cout + k)
+    x = torch.randn(B, C_, H, W, generator=gen)
+    x[0, :, 0, 0] = torch.linspace(-300.0, 300.0, C_)           # beyond the e4m3 range of x8 (|x| > 224): clamped, not NaN
+    x[0, :, 0, 1] = torch.logspace(-7, 0, C_, base=10.0)        # tiny activations: subnormal / zero e4m3 codes
+    w = torch.randn(cout, C_, k, k, generator=gen) * (2.0 / (C_ * k * k)) ** 0.5
+    w[0, 0] = 20.0                                              # beyond the range of w8 (|w| > 14)
+    ld = 2 * C_
+    g8 = ops.geom(B, H, W, k, 2 * C_, cout, ld, x_f8=C_)
+    assert ops.conv_fwd_f8_ok(g8)
+    assert tuple(ops.tile_info(g8)[:2]) == tile and ops.tile_info(g8)[3] == 2
+    # activation storage by the production pass: identity BatchNorm (scale 1, shift 0), slope 1
+    xd = x.to(dev)
+    y32 = xd.permute(0, 2, 3, 1).contiguous().view(-1)
+    one, zero = torch.ones(C_, device=dev), torch.zeros(C_, device=dev)
+    xb = ops.alloc_padded(B, H, W, ld, dev)
+    ops.bn_act_fwd(B, H, W, C_, y32, C_, 0, one, zero, 1.0, L.DST_PLAIN, xb, ld, 0, planes=4, dst_plane=C_)
+    v = ops.padded_view(xb, B, H, W, ld)[:, 1:-1, 1:-1]
+    hi = x.half()
+    assert torch.equal(v[..., :C_].permute(0, 3, 1, 2).cpu(), hi)
+    v8 = ops.padded_view(xb.view(torch.uint8), B, H, W, 2 * ld, pad=0)[:, 1:-1, 1:-1]
+    lo8, lo8_d = _e4m3(x - hi.float(), 12)
+    x8, x8_d = _e4m3(x, 1)
+    assert torch.equal(v8[..., 2 * C_:3 * C_].permute(0, 3, 1, 2).cpu(), lo8.view(torch.uint8))
+    assert torch.equal(v8[..., 3 * C_:4 * C_].permute(0, 3, 1, 2).cpu(), x8.view(torch.uint8))
+    assert not torch.isnan(x8_d).any() and float(x8_d.abs().max()) == 448.0
+    # weights by the production packer
+    wp = torch.zeros(ops.packed_elems(ops.geom(B, H, W, k, 3 * C_, cout, ld))[0], dtype=torch.float16, device=dev)
+    ops.pack_many(*ops.pack_table([dict(w=w.to(dev).contiguous(), mask=None, rows=None, cols=None, cout=cout, cin=C_, ksize=k,
+                                        dst_fwd=wp, dst_dgrad=None, split=2)], dev))
+    y = torch.full((B * H * W * cout,), float("nan"), device=dev)
+    rows = ops.stats_rows(g8, L.EPI_RAW_F32)
+    stats = torch.zeros(rows, 2, ops.round_up(cout, 256), device=dev)
+    ops.conv_fwd_raw32(g8, xb, wp, y, cout, 0, stats)
+    got = y.view(B, H, W, cout).permute(0, 3, 1, 2).double()
+    w_hi = w.half()
+    _, w8_d = _e4m3(w_hi.float(), 5)
+    _, wl8_d = _e4m3(w - w_hi.float(), 16)
+    pad = (k - 1) // 2
+    conv = lambda a, b: F.conv2d(a.to(dev).double(), b.to(dev).double(), None, 1, pad)
+    same = conv(hi, w_hi) + 2.0 ** -17 * (conv(lo8_d, w8_d) + conv(x8_d, wl8_d))
+    assert rel_l2(got, same) < 2e-6
+    full = conv(x, w)
+    plain = conv(hi, w_hi)
+    # accuracy against the unrounded product, outside the outputs the three out-of-range entries reach (filter 0, the
+    # 3 x 3 corner of image 0): there the clamped corrections are only partly applied -- between the two, never worse
+    # than plain operands
+    keep = torch.ones_like(full, dtype=torch.bool)
+    keep[:, 0] = False
+    keep[0, :, :3, :4] = False
+    e_f8, e_plain = rel_l2(got[keep], full[keep]), rel_l2(plain[keep], full[keep])
+    assert e_f8 < 1.5e-5 and e_plain > 1e-4, (e_f8, e_plain)
+    assert rel_l2(got[~keep], full[~keep]) <= 1.05 * rel_l2(plain[~keep], full[~keep])
+    yd = y.view(-1, cout).double()
+    assert torch.allclose(stats[:, 0, :cout].double().sum(0), yd.sum(0), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(stats[:, 1, :cout].double().sum(0), (yd * yd).sum(0), rtol=1e-5)
+    # forward-only field; shapes without the ping-pong tile are refused (and reported by the query)
+    with pytest.raises(L.McamdError):
+        ops.conv_fwd_raw(g8, xb, wp, torch.zeros(B * H * W * cout, dtype=torch.float16, device=dev), cout, 0, None)
+    small = ops.geom(2, H, W, k, 2 * C_, cout, ld, x_f8=C_)
+    assert not ops.conv_fwd_f8_ok(small)
+    with pytest.raises(L.McamdError):
+        ops.conv_fwd_raw32(small, xb, wp, y, cout, 0, None)
+
+
 @pytest.mark.parametrize("B,H,W,cout", [(2, 56, 56, 64), (3, 37, 39, 64), (2, 48, 50, 40)])
 def test_small3x3_split_kernel(dev, setenv, B, H, W, cout):
     """conv_small.hip small3x3_split_kernel -- the conv2 shape (32 -> <= 64 channels, 3x3, huge image) on split operands
