@@ -730,6 +730,36 @@ def test_yolov2_train_step_vs_oracle(dev):
         assert ge < 1.5 * gf + 5e-3, (name, ge, gf)
 
 
+def test_fp8_correction_blocks_vs_fp16_lo_planes(dev, monkeypatch):
+    """Default precision at B=16: the blocks whose forward takes the ping-pong kernel multiply their two correction products
+    on the block-scaled fp8 MFMAs (engine.Engine.f8, csrc/conv_igemm_pp.hip) -- MCAMD_F8=0 keeps them on fp16 lo planes.
+    Both meet north_star's 1e-3 on the train-mode logits against the fp32 oracle; the fp8 form pays its ~4 % residual
+    of a block's plain-operand term (amplified by the train-mode BatchNorms behind it), the fp16 form none."""
+    blocks = O.parse_cfg(YOLOV2_VOC_CFG)
+    state = O.init_state(blocks, seed=3)
+    x = torch.rand(16, 3, 416, 416, generator=torch.Generator().manual_seed(11))
+    with torch.no_grad():
+        ref = O.forward(blocks, state, x, training=True)
+    res = {}
+    for f8 in ("1", "0"):
+        monkeypatch.setenv("MCAMD_F8", f8)
+        m = nets.Darknet(YOLOV2_VOC_CFG)
+        m.load_state_dict(state)
+        m.precision = "mixed"
+        m.to(dev).train()
+        with torch.no_grad():
+            out = m(x.to(dev)).cpu()
+        eng = [e for e in m._engines.values() if e.precision == "mixed"][-1]
+        res[f8] = (out, [l.li + 1 for l in eng.layers if l.f8], [l.li + 1 for l in eng.layers if l.level == 1])
+        del m
+    assert res["1"][1] and set((3, 5, 6, 8, 9, 11, 13)) <= set(res["1"][1]) and not res["0"][1], res["1"][1]
+    assert res["1"][2] == res["0"][2]
+    e8, e16 = rel_l2(res["1"][0], ref), rel_l2(res["0"][0], ref)
+    print("train logits vs fp32 oracle at B=16: fp8 corrections %.2e (blocks %s), fp16 lo planes %.2e" % (e8, res["1"][1], e16))
+    assert e16 < e8 < 1e-3
+    assert rel_l2(res["1"][0], res["0"][0]) < 7e-4
+
+
 @pytest.mark.parametrize("masks,B,prec", [(None, 64, "fp16"), ("filter40", 32, "fp16"), (None, 64, "auto")],
                          ids=["dense-b64", "filter40-b32", "dense-b64-default-precision"])
 def test_training_step_is_bit_reproducible(dev, masks, B, prec):
