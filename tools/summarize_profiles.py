@@ -10,6 +10,18 @@ def one(pat):
 st = one("stats/*/*kernel_stats.csv")
 shutil.copy(st, "profiles/%s_kernel_stats.csv" % tag)
 shutil.copy(os.path.join(src, "layer_table.txt"), "profiles/%s_layer_table.txt" % tag)
+# the same statistics as a readable table (VERDICT r03 asked for `<tag>_mixed_step_kernel_summary.txt`): the bench command
+# runs 2 warm-up + 5 timed + 5 instrumented steps in the DEFAULT precision (`mixed`) = 12 steps, + 1 parity forward
+with open("profiles/%s_mixed_step_kernel_summary.txt" % tag, "w") as f:
+    rows = list(csv.DictReader(open(st)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    f.write("rocprofv3 --kernel-trace --stats of `bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-tolerance-mode` (default precision: mixed,\n"
+            "weight gradients serialised onto the launch stream); source: profiles/%s_kernel_stats.csv\n\n" % tag)
+    f.write("%-110s %7s %10s %10s %6s\n" % ("kernel", "calls", "total ms", "avg us", "%"))
+    for r in rows[:40]:
+        f.write("%-110s %7d %10.3f %10.1f %6.2f\n" % (r["Name"][:110], int(r["Calls"]), float(r["TotalDurationNs"]) / 1e6,
+                                                     float(r["AverageNs"]) / 1e3, 100.0 * float(r["TotalDurationNs"]) / tot))
+    f.write("\nall kernels: %.3f ms\n" % (tot / 1e6))
 def pmc(sub):
     rows = list(csv.DictReader(open(one(sub + "/*/*counter_collection.csv"))))
     disp = collections.defaultdict(dict)
