@@ -20,6 +20,9 @@ ks.sort()
 starts = [i for i, k in enumerate(ks) if k[2].startswith("nchw_to_nhwc_kernel") or "nchw_to_nhwc_kernel" in k[2]]
 # two layout launches per step (image in forward, logit gradient in backward): take every second one
 starts = starts[0::2]
+split = [i for i, k in enumerate(ks) if "nhwc4_split_kernel" in k[2]]
+if split:       # default precision: forward starts with the hi / lo image split, the only layout launch left is backward's
+    starts = split
 if len(starts) < nsteps + 1:
     print("only %d steps in the trace" % (len(starts) - 1))
     nsteps = len(starts) - 1

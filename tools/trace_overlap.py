@@ -18,6 +18,9 @@ f = sorted(glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=Tru
 rows = list(csv.DictReader(open(f)))
 ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0], r.get("Queue_Id", "0")) for r in rows)
 starts = [i for i, k in enumerate(ks) if "nchw_to_nhwc_kernel" in k[2]][0::2]
+split = [i for i, k in enumerate(ks) if "nhwc4_split_kernel" in k[2]]
+if split:       # default precision: forward starts with the hi / lo image split, the only layout launch left is backward's
+    starts = split
 nsteps = min(nsteps, len(starts) - 1)
 for st in range(len(starts) - 1 - nsteps, len(starts) - 1):
     win = ks[starts[st]:starts[st + 1]]
