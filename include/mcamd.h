@@ -89,7 +89,8 @@ typedef struct mcamd_conv_geom {
                              the packed weights [w_hi | w8 = e4m3(w_hi * 2^5) | wlo8 = e4m3(w_lo * 2^16)] (mcamd_pack_job.split 2):
                              y = x_hi w_hi (fp16 MFMA) + 2^-17 (lo8 w8 + x8 wlo8) (block-scaled fp8 MFMA at twice the fp16
                              rate, same fp32 accumulators) -- x w to ~2^-15 instead of plain fp16's 2^-11, at 2/3 of the
-                             x_wrap form's MFMA time and staged bytes.  Epilogue mode MCAMD_EPI_RAW_F32; only shapes for
+                             x_wrap form's MFMA time and staged bytes.  x_choff = 0 (the e4m3 strings are addressed from the
+                             pixel's first channel, also by a concat member writing at its offset).  Epilogue mode MCAMD_EPI_RAW_F32; only shapes for
                              which mcamd_conv_fwd_f8_ok() returns 1 (the ping-pong implicit-GEMM tiles).  Replaces the same
                              F.conv2d (reference src/pruning/weightPruning/layers.py:60-64). */
 } mcamd_conv_geom;

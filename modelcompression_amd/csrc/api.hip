@@ -62,8 +62,9 @@ static int check_geom(const mcamd_conv_geom* g, const char* what) {
                       g->x_choff, g->x_choff + span, g->x_ld);
     }
     if (g->x_f8 != 0) {
-        MCAMD_REQUIRE(!g->stem && g->x_wrap == 0 && g->x_f8 > 0 && g->x_f8 % 64 == 0 && g->cin == 2 * g->x_f8,
-                      "%s: x_f8 %d needs cin = 2 P with P %% 64 == 0, no x_wrap (cin %d)", what, g->x_f8, g->cin);
+        MCAMD_REQUIRE(!g->stem && g->x_wrap == 0 && g->x_f8 > 0 && g->x_f8 % 64 == 0 && g->cin == 2 * g->x_f8 && g->x_choff == 0,
+                      "%s: x_f8 %d needs cin = 2 P with P %% 64 == 0, no x_wrap, x_choff 0 (cin %d, x_choff %d)", what, g->x_f8, g->cin,
+                      g->x_choff);
     }
     if (g->x_wrap != 0) {
         const int ct = cin_tap_of(g), kb = ct % 64 == 0 ? 64 : 32;   // kblock_of(ct)
@@ -481,7 +482,7 @@ extern "C" int32_t mcamd_conv_stats_rows_mode(const mcamd_conv_geom* g, int32_t 
 }
 
 extern "C" int32_t mcamd_conv_fwd_f8_ok(const mcamd_conv_geom* g) {
-    if (!g || g->x_f8 <= 0 || g->x_f8 % 64 != 0 || g->cin != 2 * g->x_f8 || g->stem || g->x_wrap != 0) return 0;
+    if (!g || g->x_f8 <= 0 || g->x_f8 % 64 != 0 || g->cin != 2 * g->x_f8 || g->stem || g->x_wrap != 0 || g->x_choff != 0) return 0;
     return mcamd_igemm_f8_ok((long long)g->B * g->H * g->W, g->cout, cin_tap_of(g), ntaps_of(g) * cin_tap_of(g)) ? 1 : 0;
 }
 
