@@ -35,7 +35,7 @@
 //
 // F8 (round 4, the split-operand forward of the default precision): the K loop's tail is the fp8 CORRECTION part of
 // the product.  x*w = x_hi*w_hi + (x_lo*w_hi + x_hi*w_lo) + O(2^-22): the bracket is 2^-11 of the result, so its operands
-// need 3-4 bits, not 11 -- e4m3 copies [lo8 | x8] of the activation and [w8 | wlo8] of the weights (kernels.h: scales),
+// need 3-4 bits, not 11 -- e4m3 copies [lo8 | x8] of the activation and [w8 | wlo8] of the weights (common.h: scales),
 // multiplied by v_mfma_scale_f32_32x32x64_f8f6f4 INTO THE SAME ACCUMULATORS (the C/D layout is shape-determined), whose
 // e8m0 scale operands take the 2^17 back.  A 64-byte LDS row that holds 32 fp16 k's of an fp16 chunk holds 64 e4m3 k's
 // of an fp8 chunk; the concatenation of the two k16-step fragments a lane reads from it (bytes [16h, 16h+16) and
@@ -43,8 +43,8 @@
 // (any k permutation common to both sums the same products; tools/f8_probe.hip).  DMA, swizzle, ring, barriers and the
 // fragment reads are byte-identical to the fp16 chunks: only the matrix phase differs -- ONE 32x32x64 fp8 MFMA per block
 // instead of two 32x32x16 fp16 ones, the same cycles for twice the k's.  Three products cost 2 instead of 3 units of
-// MFMA time and of staged bytes.  Residual: the bracket's relative error 2^-4 / sqrt(3) per operand, ~5 % of what plain
-// fp16 operands lose.
+// MFMA time and of staged bytes.  Residual: the e4m3 rounding of the bracket's operands, ~4 % of what plain fp16
+// operands lose (measured per kernel and per block: DESIGN.md 3d).
 //
 // Operand addressing, LDS swizzle (on the DMA source), persistent M tiles per N tile, BatchNorm partial
 // sums and the epilogues are those of conv_igemm.hip.  Replaces F.conv2d at reference
