@@ -4,6 +4,9 @@
 //     kernel reads from a 64-byte K row (lane (r, h): bytes [16h, 16h+16) and [32+16h, 32+16h+16) of row r) sums
 //     every k exactly once when A and B are gathered the same way; uniform e8m0 scales multiply the product
 //  3. issue rate of the scaled fp8 form against v_mfma_f32_32x32x16_f16
+// build + run:  hipcc --offload-arch=gfx950 -O3 -o tools/f8_probe tools/f8_probe.hip && gpurun -- ./tools/f8_probe
+// measured (MI355X): 1.0 -> 0x38, 448 -> 0x7e, 480 and above -> 0x7f (NaN: the kernels clamp first); exact integer products
+// reproduced with scales (127, 127), (124, 128), (115, 122); 4 957 TFLOP/s against 2 101 for the fp16 form on constant data
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
