@@ -143,6 +143,28 @@ def test_library_exports_every_declared_symbol():
     assert lib.mcamd_last_error() is not None
 
 
+def test_fp8_correction_geometry_query():
+    """mcamd_conv_fwd_f8_ok (host logic only, no launch): the fp8-correction forward exists for a layer whose three-product
+    problem takes the ping-pong tile and whose hi plane is whole 64-channel blocks from channel 0 -- YOLOv2's conv14 and
+    conv3 at B=64 do, the same layers at B=2 (too few tiles), ragged planes, a channel offset, a wrapped geometry or a
+    mismatched channel count do not.  The statistics slab and the tile are those of the three-product form of the layer."""
+    from modelcompression_amd import ops
+    L = _lib
+    ok = ops.geom(64, 13, 13, 3, 2 * 512, 1024, 2 * 512, x_f8=512)
+    assert ops.conv_fwd_f8_ok(ok)
+    assert ops.conv_fwd_f8_ok(ops.geom(64, 104, 104, 3, 2 * 64, 128, 2 * 64, x_f8=64))
+    for bad in (ops.geom(2, 13, 13, 3, 2 * 512, 1024, 2 * 512, x_f8=512),               # 2 x 4 tiles: the 128-wide kernel
+                ops.geom(64, 13, 13, 3, 2 * 480, 1024, 2 * 480, x_f8=480),              # plane not a multiple of 64
+                ops.geom(64, 13, 13, 3, 2 * 512, 1024, 2 * 512 + 64, 64, x_f8=512),     # slice not at channel 0
+                ops.geom(64, 13, 13, 3, 3 * 512, 1024, 2 * 512, x_f8=512),              # cin != 2 P
+                ops.geom(64, 13, 13, 3, 2 * 512, 1024, 2 * 512, x_wrap=1024, x_f8=512),  # both forms at once
+                ops.geom(64, 13, 13, 3, 2 * 512, 64, 2 * 512, x_f8=512)):               # 64 filters: no ping-pong tile
+        assert not ops.conv_fwd_f8_ok(bad)
+    three = ops.geom(64, 13, 13, 3, 3 * 512, 1024, 2 * 512, x_wrap=1024)
+    assert ops.stats_rows(ok, L.EPI_RAW_F32) == ops.stats_rows(three, L.EPI_RAW_F32)
+    assert ops.tile_info(ok) == ops.tile_info(three) and ops.tile_info(ok)[3] == 2
+
+
 def test_region_loss_runs_and_has_reference_quirks():
     from modelcompression_amd.region_loss import RegionLoss
     loss = RegionLoss()
