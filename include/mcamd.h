@@ -432,15 +432,6 @@ int mcamd_stem_block_bwd(const mcamd_stem_block_desc* d, void* workspace, size_t
  * mcamd_bn_coeffs takes, as mcamd_conv_epilogue.stats.  nn.BatchNorm2d's batch statistics (src/nets.py:802). */
 int32_t mcamd_stem_block_stats_rows(const mcamd_stem_block_desc* d);
 int mcamd_stem_block_stats(const mcamd_stem_block_desc* d, float* stats, int32_t stats_rows, int32_t stats_ld, void* stream);
-/* The same statistics WITHOUT that pass (the engine's path since the end of round 4): after a training-mode
- * mcamd_stem_block_fwd on the plain operands (dst may be NULL), whose Gram sums of the fp16 image are still in
- * `workspace`, BatchNorm coefficients of the split-operand block from the SAME Gram matrix with W = wp + wp_lo
- * (mean_n = W[n].S / M, E[y^2]_n = W[n]^T C W[n] / M in double).  What it leaves out is the image residual x_lo: an unbiased
- * rounding error of 2^-12 whose window sums and whose correlation with x_hi average out over the B H W pixels -- mean and
- * variance move by ~1e-7 relative (tests: against float64 torch on the fp32 image and weights).  Writes scale / shift /
- * save_mean / save_invstd, updates running_mean / running_var (momentum) when given; the workspace context the backward
- * pass reads is left as the plain call wrote it. */
-int mcamd_stem_block_split_coeffs(const mcamd_stem_block_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Layout conversion at the model boundary (Darknet.forward takes/returns NCHW fp32,

@@ -131,7 +131,6 @@ SIGNATURES = {
     "mcamd_stem_block_bwd": (C.c_int, [C.POINTER(StemBlockDesc), _P, _SZ, _P]),
     "mcamd_stem_block_stats_rows": (_I32, [C.POINTER(StemBlockDesc)]),
     "mcamd_stem_block_stats": (C.c_int, [C.POINTER(StemBlockDesc), _P, _I32, _I32, _P]),
-    "mcamd_stem_block_split_coeffs": (C.c_int, [C.POINTER(StemBlockDesc), _P, C.c_size_t, _P]),
     "mcamd_nchw_f32_to_nhwc4_split": (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _P]),
     "mcamd_pack_stem_split": (C.c_int, [_P, _P, _I32, _P, _P, _P]),
     "mcamd_nchw_f32_to_padded_nhwc_f16": (C.c_int, [_P, _I32, _I32, _I32, _I32, _F, _P, _I32, _I32, _P, _P]),

@@ -230,15 +230,10 @@ __device__ __forceinline__ int slot48(int ty, int tx, int c) { return ty * 16 + 
 
 // Batch statistics of y = W v from the Gram matrix -> BatchNorm coefficients; keeps S and W C for the backward pass.
 // ctx (double): [0, 27) S, [32, 32 + 32*27) (W C)[n][k27], k27 = (ty*3 + tx)*3 + c.
-// wl != NULL (round 4): the statistics of the SPLIT-operand block from the same Gram matrix -- W = w_hi + w_lo.  The Gram
-// matrix is that of the fp16 image: the image residual x_lo = x - fp16(x) is an unbiased rounding error of 2^-12, its
-// window sums and its correlation with x_hi average out over the B H W pixels (mean and variance of y move by ~1e-7
-// relative), so the pass over the split image that only produced these two sums per channel is not needed
-// (mcamd_stem_block_split_coeffs).  ctx == NULL: coefficients only (the context stays the plain block's, for backward).
 __global__ __launch_bounds__(1024) void stem_coeffs_kernel(const double* csum, const half_t* wp, double count, const float* gamma,
                                                            const float* beta, float* rmean, float* rvar, float momentum,
                                                            float eps, float* scale, float* shift, float* save_mean,
-                                                           float* save_invstd, double* ctx, const half_t* wl = nullptr) {
+                                                           float* save_invstd, double* ctx) {
     __shared__ double C[48 * 48];
     __shared__ double Wd[32][28], WC[32][28], S[28];
     const int t = threadIdx.x;
@@ -247,13 +242,12 @@ __global__ __launch_bounds__(1024) void stem_coeffs_kernel(const double* csum, c
         const int n = t / 27, k = t - n * 27;
         const int ty = k / 9, tx = (k / 3) % 3, c = k % 3;
         Wd[n][k] = (double)(float)wp[n * 96 + ty * 32 + tx * 4 + c];
-        if (wl) Wd[n][k] += (double)(float)wl[n * 96 + ty * 32 + tx * 4 + c];
     }
     __syncthreads();
     if (t < 27) {
         const int ty = t / 9, tx = (t / 3) % 3, c = t % 3;
         S[t] = C[slot48(ty, tx, c) * 48 + slot48(ty, tx, 3)];
-        if (ctx) ctx[t] = S[t];
+        ctx[t] = S[t];
     }
     if (t < 864) {
         const int n = t / 27, k = t - n * 27;
@@ -261,7 +255,7 @@ __global__ __launch_bounds__(1024) void stem_coeffs_kernel(const double* csum, c
         double acc = 0.0;
         for (int k2 = 0; k2 < 27; ++k2) acc += Wd[n][k2] * C[slot48(k2 / 9, (k2 / 3) % 3, k2 % 3) * 48 + sk];
         WC[n][k] = acc;
-        if (ctx) ctx[32 + n * 27 + k] = acc;
+        ctx[32 + n * 27 + k] = acc;
     }
     __syncthreads();
     if (t < 32) {
@@ -789,29 +783,6 @@ extern "C" int mcamd_stem_block_fwd(const mcamd_stem_block_desc* d, void* worksp
     else if (d->planes == 2) hipLaunchKernelGGL((stem_block_fwd_kernel<2, 2>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((stem_block_fwd_kernel<4, 1>), dim3(grid), dim3(256), 0, st, a);   // 4 units in flight per wave (1 / 2 / 4: 66 / 62 / 60 us)
     MCAMD_LAUNCH_CHECK("stem_block_fwd");
-    return MCAMD_OK;
-}
-
-extern "C" int mcamd_stem_block_split_coeffs(const mcamd_stem_block_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
-    if (mcamd_recording()) {
-        MCAMD_REQUIRE(d, "stem_block_split_coeffs: null descriptor");
-        const mcamd_stem_block_desc d_ = *d;
-        return mcamd_rec_push(stream, [=](void* s) { return mcamd_stem_block_split_coeffs(&d_, workspace, workspace_bytes, s); });
-    }
-    if (check_desc(d, "stem_block_split_coeffs")) return MCAMD_EINVAL;
-    MCAMD_REQUIRE(workspace && d->wp_lo && d->gamma && d->beta && d->scale && d->shift && d->save_mean && d->save_invstd,
-                  "stem_block_split_coeffs: null argument");
-    MCAMD_REQUIRE(d->cout == 0 || d->cout == 32, "stem_block_split_coeffs: 32 filters");
-    const Carve c = carve();
-    if (workspace_bytes < c.total) {
-        mcamd_set_error("stem_block_split_coeffs: workspace %zu < %zu bytes", workspace_bytes, c.total);
-        return MCAMD_EWORKSPACE;
-    }
-    char* ws = (char*)workspace;
-    hipLaunchKernelGGL(stem_coeffs_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const double*)(ws + c.gram_sum),
-                       (const half_t*)d->wp, (double)d->B * d->H * d->W, d->gamma, d->beta, d->running_mean, d->running_var,
-                       d->momentum, d->eps, d->scale, d->shift, d->save_mean, d->save_invstd, (double*)nullptr, (const half_t*)d->wp_lo);
-    MCAMD_LAUNCH_CHECK("stem_block_split_coeffs");
     return MCAMD_OK;
 }
 

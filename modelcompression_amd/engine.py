@@ -449,9 +449,8 @@ class Engine:
                                        and lay.cout in (8, 16, 24) and lay.W % 32 == 0 and lay.H % 2 == 0 and lay.border is None)
             lay.stem_shadow = bool(li_is_first(lay) and self.stem_shadow and lay.bn is not None and lay.mode == L.DST_POOL
                                    and lay.out2_id is None and lay.cout == 32 and lay.border is None)
-            # ... and (round 4) its FORWARD pass is the fused first block too, on SPLIT operands: batch statistics (from a
-            # pass over the hi / lo NHWC4 images that wrote nothing but per-channel sums; since the end of the round from the
-            # plain block's Gram sums with W = w_hi + w_lo), then conv + BatchNorm + LeakyReLU + MaxPool
+            # ... and (round 4) its FORWARD pass is the fused first block too, on SPLIT operands: a statistics pass over the
+            # hi / lo NHWC4 images that writes nothing but per-channel sums, then conv + BatchNorm + LeakyReLU + MaxPool
             # recomputed and written once as the pooled hi | lo planes (csrc/conv_stem_block.hip, SPLIT).  Replaces the fp32
             # first convolution's 1.4 GB raw output, its BatchNorm pass and the scratch forward of the plain block:
             # 1.16 -> 0.41 ms per B=64 step (13.85 -> 12.98 ms, A/B on one box).
@@ -487,7 +486,7 @@ class Engine:
                     lay.y = None if lay.stem_split else torch.zeros(lay.M * lay.cout, dtype=torch.float32 if self.precise else ops.HALF,
                                                                     device=dev)
                     if lay.stem_split:
-                        lay.stats = None              # (statistics from the Gram sums: _stem_split_forward)
+                        lay.stats = torch.zeros(ops.stem_block_stats_rows(B, lay.H, lay.W), 2, ops.round_up(lay.cout, 256), **f32)
                     elif lay.stem_f32:
                         lay.stats = torch.zeros(ops.stem_conv_f32_stats_rows(), 2, ops.round_up(lay.cout, 256), **f32)
                         lay.weff = torch.empty(lay.cout * 27, **f32)
@@ -1073,16 +1072,13 @@ class Engine:
                            dst_pad=self._pad_for(t.W), dst2_pad=self._pad_for(t2.W) if t2 is not None else 0)
 
     def _stem_split_forward(self, lay):
-        """The first block of the "mixed" training precision: BatchNorm coefficients of the split-operand conv output,
-        then conv + BatchNorm + LeakyReLU + MaxPool computed into the consumer's hi | lo planes (nothing else stored)."""
+        """The first block of the "mixed" training precision: batch statistics of the split-operand conv output (nothing
+        stored), coefficients, then conv + BatchNorm + LeakyReLU + MaxPool recomputed into the consumer's hi | lo planes."""
         bn, t = lay.bn, lay.out_t
-        # batch statistics of the split-operand conv output from the Gram sums the plain-operand call just left in the
-        # workspace, with W = w_hi + w_lo (mcamd_stem_block_split_coeffs): the pass over the split image that produced
-        # them until the end of round 4 (mcamd_stem_block_stats, 0.11 ms) moved mean / invstd by 1e-6 and nothing else --
-        # 11.54 -> 11.42-11.44 ms per step, train logits unchanged (7.68e-4 / 7.28e-4 on two seeds either way)
-        ops.stem_block_split_coeffs(self.B, lay.H, lay.W, lay.sh_img, lay.sh_wp, lay.sh_wp_lo, bn.weight.data, bn.bias.data,
-                                    bn.running_mean, bn.running_var, lay.scale, lay.shift, lay.mean, lay.invstd, lay.slope,
-                                    lay.stem_ws, momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps)
+        ops.stem_block_stats(self.B, lay.H, lay.W, lay.sh_img, lay.sh_wp, lay.stats, x_lo=lay.sh_img_lo, wp_lo=lay.sh_wp_lo)
+        ops.bn_coeffs(lay.stats, lay.cout, lay.M, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, True,
+                      lay.scale, lay.shift, lay.mean, lay.invstd, momentum=bn.momentum if bn.momentum is not None else 0.1,
+                      eps=bn.eps)
         ops.stem_block_fwd(self.B, lay.H, lay.W, lay.sh_img, lay.sh_wp, bn.weight.data, bn.bias.data, None, None, False,
                            lay.scale, lay.shift, lay.mean, lay.invstd, lay.slope, self.bufs[t.buf], t.ld, t.choff, None,
                            eps=bn.eps, cout=lay.cout, planes=self.act_planes, x_lo=lay.sh_img_lo, wp_lo=lay.sh_wp_lo)

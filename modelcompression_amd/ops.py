@@ -419,19 +419,6 @@ def stem_block_stats(B, H, W, x, wp, stats, x_lo=None, wp_lo=None):
           "mcamd_stem_block_stats")
 
 
-def stem_block_split_coeffs(B, H, W, x, wp, wp_lo, gamma, beta, rmean, rvar, scale, shift, mean, invstd, slope, workspace,
-                            momentum=0.1, eps=1e-5):
-    """BatchNorm coefficients of the first block on SPLIT operands from the Gram sums a training-mode stem_block_fwd call on
-    the plain operands left in `workspace` (W = wp + wp_lo; mcamd_stem_block_split_coeffs): no pass over the image."""
-    d = _stem_desc(B, H, W, x, wp, gamma, beta, scale, shift, mean, invstd, slope)
-    d.running_mean = rmean.data_ptr() if rmean is not None else None
-    d.running_var = rvar.data_ptr() if rvar is not None else None
-    d.momentum, d.eps, d.training, d.cout = momentum, eps, 1, 32
-    d.wp_lo = wp_lo.data_ptr()
-    check(L.lib().mcamd_stem_block_split_coeffs(C.byref(d), ptr(workspace), workspace.numel(), stream_ptr()),
-          "mcamd_stem_block_split_coeffs")
-
-
 def nchw_to_nhwc4_split(src, hi, lo):
     """fp32 NCHW 3-channel image -> padded NHWC4 fp16 images hi = fp16(v), lo = fp16(v - hi)."""
     _need_cuda(src, hi, lo)
