@@ -86,13 +86,17 @@ typedef struct mcamd_conv_geom {
     int32_t x_f8;         /* mcamd_conv_fwd only, 0 = none.  P > 0 (P % 64 == 0, cin = 2 P, x_wrap = 0): the split-operand forward
                              with fp8 CORRECTION terms.  Channels [0, P) of the slice are the fp16 hi plane; the next P fp16
                              units hold 2 P OCP-e4m3 bytes [lo8 = e4m3(x_lo * 2^12) | x8 = e4m3(x * 2)] (mcamd_act_desc.planes 4),
-                             the packed weights [w_hi | w8 = e4m3(w_hi * 2^5) | wlo8 = e4m3(w_lo * 2^16)] (mcamd_pack_job.split 2):
-                             y = x_hi w_hi (fp16 MFMA) + 2^-17 (lo8 w8 + x8 wlo8) (block-scaled fp8 MFMA at twice the fp16
+                             the packed weights [w_hi | w8 = e4m3(w_hi * 2^e) | wlo8 = e4m3(w_lo * 2^(e + 11))], e = x_f8_wexp (mcamd_pack_job.split 2):
+                             y = x_hi w_hi (fp16 MFMA) + 2^-(12 + e) (lo8 w8 + x8 wlo8) (block-scaled fp8 MFMA at twice the fp16
                              rate, same fp32 accumulators) -- x w to ~2^-15 instead of plain fp16's 2^-11, at 2/3 of the
                              x_wrap form's MFMA time and staged bytes.  x_choff = 0 (the e4m3 strings are addressed from the
                              pixel's first channel, also by a concat member writing at its offset).  Epilogue mode MCAMD_EPI_RAW_F32; only shapes for
                              which mcamd_conv_fwd_f8_ok() returns 1 (the ping-pong implicit-GEMM tiles).  Replaces the same
                              F.conv2d (reference src/pruning/weightPruning/layers.py:60-64). */
+    int32_t x_f8_wexp;    /* with x_f8: the exponent the weight bytes were packed with, w8 = e4m3(w_hi * 2^x_f8_wexp), wlo8 =
+                             e4m3(w_lo * 2^(x_f8_wexp + 11)) (mcamd_pack_job.f8_wexp; [-24, 40]).  Chosen per layer so that the
+                             largest |w| lands in the upper binades of e4m3 (448): BatchNorm makes a layer's weight scale
+                             arbitrary.  5 suits initialisation-sized weights (|w| <= 14). */
 } mcamd_conv_geom;
 int32_t mcamd_conv_fwd_f8_ok(const mcamd_conv_geom* g);   /* 1: mcamd_conv_fwd accepts this x_f8 geometry */
 
@@ -196,6 +200,8 @@ typedef struct mcamd_pack_job {
                                   3 * cin input channels.  2: the fp8-correction packing of mcamd_conv_geom.x_f8,
                                   [w_hi fp16 | w8 | wlo8 e4m3 bytes] in a row of 2 * cin fp16 units per tap (cin % 64 == 0).
                                   The dgrad packing is plain in every case. */
+    int32_t f8_wexp;           /* split 2: w8 = e4m3(w_hi * 2^f8_wexp), wlo8 = e4m3(w_lo * 2^(f8_wexp + 11)); the consumer's
+                                  mcamd_conv_geom.x_f8_wexp must say the same */
 } mcamd_pack_job;
 int mcamd_pack_weights_many(const mcamd_pack_job* jobs_dev, int32_t njobs, int64_t total_tiles, void* stream);
 

@@ -17,7 +17,7 @@ class McamdError(RuntimeError):
 class ConvGeom(C.Structure):
     _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("ksize", C.c_int32),
                 ("cin", C.c_int32), ("cout", C.c_int32), ("x_ld", C.c_int32), ("x_choff", C.c_int32),
-                ("stem", C.c_int32), ("pad", C.c_int32), ("x_wrap", C.c_int32), ("x_f8", C.c_int32)]
+                ("stem", C.c_int32), ("pad", C.c_int32), ("x_wrap", C.c_int32), ("x_f8", C.c_int32), ("x_f8_wexp", C.c_int32)]
 
 
 class ConvEpilogue(C.Structure):
@@ -47,7 +47,7 @@ class PackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("mask", C.c_void_p), ("dst_fwd", C.c_void_p), ("dst_dgrad", C.c_void_p),
                 ("rows", C.c_void_p), ("cols", C.c_void_p),
                 ("first_tile", C.c_int64), ("cout", C.c_int32), ("cin", C.c_int32), ("ksize", C.c_int32),
-                ("split", C.c_int32)]
+                ("split", C.c_int32), ("f8_wexp", C.c_int32)]
 
 
 class ActBwdDesc(C.Structure):

@@ -65,6 +65,7 @@ static int check_geom(const mcamd_conv_geom* g, const char* what) {
         MCAMD_REQUIRE(!g->stem && g->x_wrap == 0 && g->x_f8 > 0 && g->x_f8 % 64 == 0 && g->cin == 2 * g->x_f8 && g->x_choff == 0,
                       "%s: x_f8 %d needs cin = 2 P with P %% 64 == 0, no x_wrap, x_choff 0 (cin %d, x_choff %d)", what, g->x_f8, g->cin,
                       g->x_choff);
+        MCAMD_REQUIRE(g->x_f8_wexp >= -24 && g->x_f8_wexp <= 40, "%s: x_f8_wexp %d outside [-24, 40]", what, g->x_f8_wexp);
     }
     if (g->x_wrap != 0) {
         const int ct = cin_tap_of(g), kb = ct % 64 == 0 ? 64 : 32;   // kblock_of(ct)
@@ -308,8 +309,8 @@ __global__ __launch_bounds__(256) void pack_tiles_kernel(const mcamd_pack_job* j
                 for (int i = 0; i < 8; ++i) {
                     const float v = src[i * kk];
                     h[i] = (half_t)v;
-                    q8[i] = fminf(fmaxf((float)h[i] * (float)(1 << MCAMD_F8_SW8), -448.f), 448.f);
-                    ql[i] = fminf(fmaxf((v - (float)h[i]) * (float)(1 << MCAMD_F8_SWL), -448.f), 448.f);
+                    q8[i] = fminf(fmaxf(ldexpf((float)h[i], j.f8_wexp), -448.f), 448.f);
+                    ql[i] = fminf(fmaxf(ldexpf(v - (float)h[i], j.f8_wexp + 11), -448.f), 448.f);
                 }
                 *(h8_t*)(row + kpos(t, c, kk, cin_tap)) = h;
                 int w8[2], wl[2];
@@ -544,6 +545,7 @@ extern "C" int mcamd_conv_fwd(const mcamd_conv_geom* g, const void* x, const voi
                   "conv_fwd: x_wrap goes with the fp32 epilogues (modes 3 and 1)");
     // x_f8: channel blocks [P, 2 P) of the slice are e4m3 bytes; K order [channel block][tap][kb] -> the fp8 chunks are the tail
     a.f8_from = g->x_f8 > 0 ? (g->x_f8 / a.kb) * a.ntaps * (a.kb / 32) : 0x7fffffff;
+    a.f8_sb = (127 - (MCAMD_F8_SXL + g->x_f8_wexp)) * 0x01010101;
     if (g->x_f8 > 0) {
         MCAMD_REQUIRE(epi && epi->mode == MCAMD_EPI_RAW_F32, "conv_fwd: x_f8 goes with the fp32 epilogue (mode 3)");
         MCAMD_REQUIRE(mcamd_igemm_f8_ok(a.M, g->cout, a.cin_tap, a.ktot), "conv_fwd: no fp8-correction kernel for this shape (mcamd_conv_fwd_f8_ok)");

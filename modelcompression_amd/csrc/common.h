@@ -91,13 +91,14 @@ __device__ __forceinline__ int swz(int row) {
 }
 
 // Scales of the fp8 correction operands (mcamd_conv_geom.x_f8, mcamd_act_desc.planes == 4, mcamd_pack_job.split == 2):
-//   lo8 = e4m3(x_lo * 2^F8_SXL),  x8 = e4m3(x * 2^F8_SX8),  w8 = e4m3(w_hi * 2^F8_SW8),  wlo8 = e4m3(w_lo * 2^F8_SWL)
-// lo8 * w8 and x8 * wlo8 carry the same factor 2^F8_SUM, which the block-scaled MFMA takes back through its e8m0 scale
-// operands.  Ranges: |x| <= 224 and |w| <= 14 before the e4m3 maximum 448 clamps (the correction of such an entry is then
-// partly lost: never worse than plain fp16 operands); three mantissa bits down to |x| 2^-7 (x8), 2^-7 (lo8) and |w| 2^-11.
+//   lo8 = e4m3(x_lo * 2^F8_SXL),  x8 = e4m3(x * 2^F8_SX8),  w8 = e4m3(w_hi * 2^wexp),  wlo8 = e4m3(w_lo * 2^(wexp + 11))
+// lo8 * w8 and x8 * wlo8 then carry the same factor 2^(F8_SXL + wexp), which the block-scaled MFMA takes back through
+// its e8m0 scale operands.  `wexp` is a per-LAYER exponent (mcamd_pack_job.f8_wexp = mcamd_conv_geom.x_f8_wexp; the engine
+// derives it from the layer's largest weight so that it lands at 112-224 of e4m3's 448: BatchNorm makes the scale of a
+// layer's weights arbitrary, a static exponent served a 30x range either way).  Activations: |x| <= 224 before
+// the e4m3 maximum clamps (the correction of such an entry is then partly lost: never worse than plain fp16 operands);
+// three mantissa bits down to |x| 2^-7 (x8, lo8).
 #define MCAMD_F8_SXL 12
 #define MCAMD_F8_SX8 1
-#define MCAMD_F8_SW8 5
-#define MCAMD_F8_SWL 16
-#define MCAMD_F8_SUM 17
-static_assert(MCAMD_F8_SXL + MCAMD_F8_SW8 == MCAMD_F8_SUM && MCAMD_F8_SX8 + MCAMD_F8_SWL == MCAMD_F8_SUM, "one scale for both correction terms");
+#define MCAMD_F8_WEXP_DEFAULT 5      /* |w| <= 14: initialisation-sized weights */
+static_assert(MCAMD_F8_SXL == MCAMD_F8_SX8 + 11, "one scale for both correction terms: w_lo is scaled 2^11 above w_hi");

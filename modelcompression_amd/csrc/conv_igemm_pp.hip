@@ -37,7 +37,7 @@
 // the product.  x*w = x_hi*w_hi + (x_lo*w_hi + x_hi*w_lo) + O(2^-22): the bracket is 2^-11 of the result, so its operands
 // need 3-4 bits, not 11 -- e4m3 copies [lo8 | x8] of the activation and [w8 | wlo8] of the weights (common.h: scales),
 // multiplied by v_mfma_scale_f32_32x32x64_f8f6f4 INTO THE SAME ACCUMULATORS (the C/D layout is shape-determined), whose
-// e8m0 scale operands take the 2^17 back.  A 64-byte LDS row that holds 32 fp16 k's of an fp16 chunk holds 64 e4m3 k's
+// e8m0 scale operands take the 2^(12 + wexp) back.  A 64-byte LDS row that holds 32 fp16 k's of an fp16 chunk holds 64 e4m3 k's
 // of an fp8 chunk; the concatenation of the two k16-step fragments a lane reads from it (bytes [16h, 16h+16) and
 // [32+16h, 32+16h+16) of row r) is a valid 32-byte operand of the 64-k instruction because A and B are gathered the same way
 // (any k permutation common to both sums the same products; tools/f8_probe.hip).  DMA, swizzle, ring, barriers and the
@@ -300,13 +300,13 @@ __global__ __launch_bounds__(512, 1) void igemm_pp_kernel(IgemmArgs a) {
             if constexpr (F8) {
                 if (IS8) {                 // fp8 correction chunk: one 64-k MFMA per block
                     did8 = true;
-                    // e8m0 scales 1 and 2^-17 (a VGPR of four scale bytes each; op_sel picks byte 0).  Inline assembly: through
+                    // e8m0 scales 1 and 2^-(12 + wexp) (a VGPR of four scale bytes each; op_sel picks byte 0).  Inline assembly: through
                     // the builtin hipcc does not accumulate in place (no tied form of the scaled instruction: every block got a
                     // second set of 16 registers and 16 v_mov back -- 256 registers + 254 spilled for the 256 x 256 tile).
                     // Hazards the assembler does not see: none inside the loop (the blocks are independent, the operands come
                     // from LDS reads retired before the barrier, the next reader of an accumulator is an MFMA two barriers
                     // later); the epilogue's VALU reads are padded after the loop.
-                    const int SA = 127 * 0x01010101, SB = (127 - MCAMD_F8_SUM) * 0x01010101;
+                    const int SA = 127 * 0x01010101, SB = a.f8_sb;
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll

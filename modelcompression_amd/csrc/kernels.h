@@ -37,6 +37,7 @@ struct IgemmArgs {
     int concurrent;  // mcamd_conv_epilogue.concurrent (dgrad): tiles chosen for CU-time, see pick_tile
     int wrap;        // mcamd_conv_geom.x_wrap (INT_MAX = none): channel blocks >= wrap are read `wrap` channels lower
     int f8_from;     // mcamd_conv_geom.x_f8: first K chunk (of 32 fp16 = 64 e4m3 values) of the fp8 correction part; INT_MAX = none
+    int f8_sb;       // e8m0 scale of the B operand of the fp8 MFMAs in all four bytes: 2^-(F8_SXL + x_f8_wexp) (A: 1.0)
 };
 
 

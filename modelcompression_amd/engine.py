@@ -21,6 +21,7 @@ Activations live in HBM as padded NHWC fp16 for the whole step; weights are re-p
 batch size; a B=64 training step holds ~7 GB of the 288 GB.
 """
 import contextlib
+import math
 import os
 import time
 
@@ -430,7 +431,7 @@ class Engine:
             lay.geom_f = g if lay.level == 1 else ops.geom(B, lay.H, lay.W, lay.k, lay.level * lay.cin, lay.cout,
                                                            lay.tin.ld, 0, 0, lay.pad, wrap)
             nf, _ = ops.packed_elems(lay.geom_f)
-            lay.f8 = False
+            lay.f8, lay.f8_wexp, lay.f8_wexp_eff = False, ops.F8_WEXP_DEFAULT, ops.F8_WEXP_DEFAULT
             if self.precise:
                 lay.n_act, lay.geom_act = lay.cout, g
                 self._set_geom_f(lay)
@@ -604,6 +605,8 @@ class Engine:
         sig = self._signature()
         if not force and sig == self._packed_sig and not self.model._weights_dirty:
             return
+        if self.model._weights_dirty:
+            self._refresh_f8_wexp()
         mkeys = tuple(None if not lay.conv.mask_flag else (lay.conv.mask.data_ptr(), lay.conv.mask._version)
                       for lay in self.layers)
         if mkeys != self._mask_keys:         # masks are static during retraining: planned once
@@ -634,10 +637,10 @@ class Engine:
                 split = 2 if lay.f8 else (1 if lay.level == 3 else 0)      # mcamd_pack_job.split
                 if lay.fold is not None:     # augmented weights (kept inputs + the folded ones-channel), rebuilt per step
                     jobs.append(dict(w=lay.waug, mask=None, rows=None, cols=None, cout=lay.n_act, cin=lay.fold_aug,
-                                     ksize=lay.k, dst_fwd=lay.wp, dst_dgrad=lay.wd, split=split))
+                                     ksize=lay.k, dst_fwd=lay.wp, dst_dgrad=lay.wd, split=split, f8_wexp=lay.f8_wexp_eff))
                     continue
                 jobs.append(dict(w=w, mask=mask, rows=lay.g_rows, cols=lay.g_cols, cout=lay.n_act, cin=lay.cin, ksize=lay.k,
-                                 dst_fwd=lay.wp, dst_dgrad=lay.wd, split=split))
+                                 dst_fwd=lay.wp, dst_dgrad=lay.wd, split=split, f8_wexp=lay.f8_wexp_eff))
             self._pack_table = ops.pack_table(jobs, self.device) if jobs else None
             self._pack_key = tkey
         for lay in self.layers:
@@ -705,9 +708,36 @@ class Engine:
         prod = self.producer_of.get(lay.src)
         if (self.f8 and wrap and prod is not None and not lay.stem and not prod.stem
                 and lay.bn is not None and cin_eff % 64 == 0 and lay.tin.ps == cin_eff and lay.tin.choff == 0):
-            g8 = ops.geom(self.B, lay.H, lay.W, lay.k, 2 * cin_eff, lay.n_act, lay.tin.ld, 0, 0, lay.pad, 0, x_f8=cin_eff)
+            # (a folding consumer's augmented weights carry the folded constants of up to cout dead channels in one column:
+            # 16x of headroom above the layer's own largest weight)
+            lay.f8_wexp_eff = lay.f8_wexp - (4 if lay.fold is not None else 0)
+            g8 = ops.geom(self.B, lay.H, lay.W, lay.k, 2 * cin_eff, lay.n_act, lay.tin.ld, 0, 0, lay.pad, 0, x_f8=cin_eff,
+                          x_f8_wexp=lay.f8_wexp_eff)
             if ops.conv_fwd_f8_ok(g8):
                 lay.f8, lay.geom_f = True, g8
+
+    def _refresh_f8_wexp(self):
+        """Per-layer exponent of the e4m3 weight bytes (mcamd_conv_geom.x_f8_wexp): the layer's largest |w| lands at
+        112-224 of e4m3's 448.  BatchNorm makes a layer's weight scale arbitrary and the bytes have 17 binades, so a static
+        exponent served initialisation-sized weights only (x 300: 5e-3 on the train logits).  One host read,
+        taken when the model says its weights were replaced (load_state_dict / load_weights / invalidate_packed, and the
+        first pack) -- not per step: SGD moves a layer's largest weight by far less than the 2x of headroom."""
+        cands = [lay for lay in self.layers if lay.level == 3 and lay.bn is not None and not lay.stem]
+        if not (self.f8 and cands):
+            return
+        amax = torch.stack([lay.conv.weight.data.abs().max() for lay in cands]).tolist()
+        changed = False
+        for lay, a in zip(cands, amax):
+            e = ops.F8_WEXP_DEFAULT
+            if a > 0.0 and math.isfinite(a):
+                e = max(-20, min(36, int(math.floor(math.log2(224.0 / a)))))
+            if e != lay.f8_wexp:
+                lay.f8_wexp, changed = e, True
+        if changed:
+            for lay in self.layers:
+                self._set_geom_f(lay)
+            self._pack_key = None
+            self._plan_epoch += 1         # the forward geometries changed: recorded plans are stale
 
     def _planes_for(self, tid):
         """Storage form of activation tensor `tid` in a split-operand engine (mcamd_act_desc.planes): 4 = hi | e4m3

@@ -78,8 +78,11 @@ def padded_view(buf, B, H, W, ld, pad=None):
     return buf[: B * (H + 2) * (W + 2) * ld].view(B, H + 2, W + 2, ld)
 
 
-def geom(B, H, W, ksize, cin, cout, x_ld, x_choff=0, stem=0, pad=0, x_wrap=0, x_f8=0):
-    return ConvGeom(B, H, W, ksize, cin, cout, x_ld, x_choff, stem, pad, x_wrap, x_f8)
+F8_WEXP_DEFAULT = 5      # weight exponent of the fp8 correction bytes for initialisation-sized weights (|w| <= 14)
+
+
+def geom(B, H, W, ksize, cin, cout, x_ld, x_choff=0, stem=0, pad=0, x_wrap=0, x_f8=0, x_f8_wexp=F8_WEXP_DEFAULT):
+    return ConvGeom(B, H, W, ksize, cin, cout, x_ld, x_choff, stem, pad, x_wrap, x_f8, x_f8_wexp if x_f8 else 0)
 
 
 def conv_fwd_f8_ok(g):
@@ -135,6 +138,7 @@ def pack_table(jobs, device):
             setattr(a, name, j[name].data_ptr() if j.get(name) is not None else None)
         a.first_tile, a.cout, a.cin, a.ksize = total, j["cout"], j["cin"], j["ksize"]
         a.split = int(j.get("split") or 0)      # 0 plain, 1 [w_hi | w_hi | w_lo], 2 [w_hi | w8 | wlo8] (mcamd_pack_job.split)
+        a.f8_wexp = int(j.get("f8_wexp", F8_WEXP_DEFAULT))
         total += ((j["cout"] + 31) // 32) * ((j["cin"] + 31) // 32)
     host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
     return host.to(device), len(jobs), total

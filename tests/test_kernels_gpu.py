@@ -419,9 +419,11 @@ def _e4m3(v, scale):
     return q, q.to(torch.float64)
 
 
-@pytest.mark.parametrize("B,H,W,C_,cout,k,tile", [(64, 13, 13, 128, 1024, 3, (192, 256)), (64, 52, 52, 128, 256, 3, (256, 256)),
-                                                  (16, 104, 104, 64, 128, 3, (256, 128)), (64, 13, 13, 1024, 512, 1, (192, 128))])
-def test_f8_correction_forward(dev, B, H, W, C_, cout, k, tile):
+@pytest.mark.parametrize("B,H,W,C_,cout,k,tile,wscale,wexp", [
+    (64, 13, 13, 128, 1024, 3, (192, 256), 1.0, 5), (64, 52, 52, 128, 256, 3, (256, 256), 1.0, 5),
+    (16, 104, 104, 64, 128, 3, (256, 128), 1.0, 5), (64, 13, 13, 1024, 512, 1, (192, 128), 1.0, 5),
+    (64, 13, 13, 128, 1024, 3, (192, 256), 200.0, -3), (64, 13, 13, 128, 1024, 3, (192, 256), 1.0 / 64, 11)])
+def test_f8_correction_forward(dev, B, H, W, C_, cout, k, tile, wscale, wexp):
     """mcamd_conv_geom.x_f8 (round 4): y = x_hi w_hi on the fp16 MFMAs + 2^-17 (lo8 w8 + x8 wlo8) on the block-scaled fp8
     MFMAs, in the four ping-pong tiles.  Operands are made by the production kernels: the activation pass with
     mcamd_act_desc.planes = 4 (hi | [lo8 | x8], checked byte for byte against torch's float8_e4m3fn) and the one-launch
@@ -432,10 +434,12 @@ def test_f8_correction_forward(dev, B, H, W, C_, cout, k, tile):
     x = torch.randn(B, C_, H, W, generator=gen)
     x[0, :, 0, 0] = torch.linspace(-300.0, 300.0, C_)           # beyond the e4m3 range of x8 (|x| > 224): clamped, not NaN
     x[0, :, 0, 1] = torch.logspace(-7, 0, C_, base=10.0)        # tiny activations: subnormal / zero e4m3 codes
-    w = torch.randn(cout, C_, k, k, generator=gen) * (2.0 / (C_ * k * k)) ** 0.5
-    w[0, 0] = 20.0                                              # beyond the range of w8 (|w| > 14)
+    # `wscale`: BatchNorm makes a layer's weight scale arbitrary; the packer and the geometry carry a per-layer exponent
+    # `wexp` (mcamd_pack_job.f8_wexp = mcamd_conv_geom.x_f8_wexp) that puts the largest weights into e4m3's upper binades
+    w = torch.randn(cout, C_, k, k, generator=gen) * (2.0 / (C_ * k * k)) ** 0.5 * wscale
+    w[0, 0] = 20.0 * wscale                                     # beyond the range of w8 (|w| 2^wexp > 448)
     ld = 2 * C_
-    g8 = ops.geom(B, H, W, k, 2 * C_, cout, ld, x_f8=C_)
+    g8 = ops.geom(B, H, W, k, 2 * C_, cout, ld, x_f8=C_, x_f8_wexp=wexp)
     assert ops.conv_fwd_f8_ok(g8)
     assert tuple(ops.tile_info(g8)[:2]) == tile and ops.tile_info(g8)[3] == 2
     # activation storage by the production pass: identity BatchNorm (scale 1, shift 0), slope 1
@@ -456,18 +460,18 @@ def test_f8_correction_forward(dev, B, H, W, C_, cout, k, tile):
     # weights by the production packer
     wp = torch.zeros(ops.packed_elems(ops.geom(B, H, W, k, 3 * C_, cout, ld))[0], dtype=torch.float16, device=dev)
     ops.pack_many(*ops.pack_table([dict(w=w.to(dev).contiguous(), mask=None, rows=None, cols=None, cout=cout, cin=C_, ksize=k,
-                                        dst_fwd=wp, dst_dgrad=None, split=2)], dev))
+                                        dst_fwd=wp, dst_dgrad=None, split=2, f8_wexp=wexp)], dev))
     y = torch.full((B * H * W * cout,), float("nan"), device=dev)
     rows = ops.stats_rows(g8, L.EPI_RAW_F32)
     stats = torch.zeros(rows, 2, ops.round_up(cout, 256), device=dev)
     ops.conv_fwd_raw32(g8, xb, wp, y, cout, 0, stats)
     got = y.view(B, H, W, cout).permute(0, 3, 1, 2).double()
     w_hi = w.half()
-    _, w8_d = _e4m3(w_hi.float(), 5)
-    _, wl8_d = _e4m3(w - w_hi.float(), 16)
+    _, w8_d = _e4m3(w_hi.float(), wexp)
+    _, wl8_d = _e4m3(w - w_hi.float(), wexp + 11)
     pad = (k - 1) // 2
     conv = lambda a, b: F.conv2d(a.to(dev).double(), b.to(dev).double(), None, 1, pad)
-    same = conv(hi, w_hi) + 2.0 ** -17 * (conv(lo8_d, w8_d) + conv(x8_d, wl8_d))
+    same = conv(hi, w_hi) + 2.0 ** -(12 + wexp) * (conv(lo8_d, w8_d) + conv(x8_d, wl8_d))
     assert rel_l2(got, same) < 2e-6
     full = conv(x, w)
     plain = conv(hi, w_hi)
@@ -481,12 +485,12 @@ def test_f8_correction_forward(dev, B, H, W, C_, cout, k, tile):
     assert e_f8 < 1.5e-5 and e_plain > 1e-4, (e_f8, e_plain)
     assert rel_l2(got[~keep], full[~keep]) <= 1.05 * rel_l2(plain[~keep], full[~keep])
     yd = y.view(-1, cout).double()
-    assert torch.allclose(stats[:, 0, :cout].double().sum(0), yd.sum(0), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(stats[:, 0, :cout].double().sum(0), yd.sum(0), rtol=1e-5, atol=4e-3 * max(1.0, wscale))
     assert torch.allclose(stats[:, 1, :cout].double().sum(0), (yd * yd).sum(0), rtol=1e-5)
     # forward-only field; shapes without the ping-pong tile are refused (and reported by the query)
     with pytest.raises(L.McamdError):
         ops.conv_fwd_raw(g8, xb, wp, torch.zeros(B * H * W * cout, dtype=torch.float16, device=dev), cout, 0, None)
-    small = ops.geom(2, H, W, k, 2 * C_, cout, ld, x_f8=C_)
+    small = ops.geom(2, H, W, k, 2 * C_, cout, ld, x_f8=C_, x_f8_wexp=wexp)
     assert not ops.conv_fwd_f8_ok(small)
     with pytest.raises(L.McamdError):
         ops.conv_fwd_raw32(small, xb, wp, y, cout, 0, None)

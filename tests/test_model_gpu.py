@@ -762,6 +762,34 @@ def test_fp8_correction_blocks_vs_fp16_lo_planes(dev, monkeypatch):
     assert rel_l2(res["1"][0], res["0"][0]) < 1.2e-3
 
 
+def test_default_precision_is_invariant_to_the_weight_scale(dev):
+    """BatchNorm makes the scale of a conv layer's weights arbitrary (the reference's logits do not move when a
+    BatchNorm-followed weight tensor is multiplied by a constant), and trained checkpoints use that freedom.  The e4m3
+    weight bytes of the fp8 correction form have 17 binades: the engine packs them with a per-LAYER exponent taken from the
+    layer's largest weight (mcamd_conv_geom.x_f8_wexp), refreshed when the model's weights are replaced.  With one static
+    exponent x 300 read 5e-3 here."""
+    blocks = O.parse_cfg(YOLOV2_VOC_CFG)
+    base = O.init_state(blocks, seed=2)
+    x = torch.rand(4, 3, 416, 416, generator=torch.Generator().manual_seed(4))
+    scaled = lambda f: {k: (v * f if (v.dim() == 4 and not k.endswith("conv23.weight")) else v.clone()) for k, v in base.items()}
+    m = nets.Darknet(YOLOV2_VOC_CFG)
+    m.load_state_dict(scaled(1.0))
+    m.to(dev).train()
+    exps = []
+    for f in (1.0, 300.0, 1.0 / 30.0):            # the same model object: load_state_dict marks the weights as replaced
+        st = scaled(f)
+        m.load_state_dict(st)
+        with torch.no_grad():
+            ref = O.forward(blocks, st, x, training=True)
+            e = rel_l2(m(x.to(dev)).cpu(), ref)
+        eng = [e_ for e_ in m._engines.values() if e_.precision == "mixed"][-1]
+        exps.append([l.f8_wexp for l in eng.layers if l.f8])
+        print("conv weights x %-7.4g train logits %.2e, exponents of the fp8 blocks %s" % (f, e, exps[-1]))
+        assert exps[-1] and e < 1e-3
+    assert all(a - b in (8, 9) for a, b in zip(exps[0], exps[1]))          # x 300 = 2^8.2
+    assert all(b - a in (4, 5) for a, b in zip(exps[0], exps[2]))          # x 1/30 = 2^-4.9
+
+
 def test_default_precision_on_8bit_images(dev):
     """north_star's 1e-3 on the train-mode logits with the inputs a dataset really delivers: 8-bit images (k / 255), here
     a DARK batch with 40 grey levels.  Such an image has one deterministic fp16 rounding error per grey level, so anything
