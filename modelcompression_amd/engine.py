@@ -605,7 +605,7 @@ class Engine:
         sig = self._signature()
         if not force and sig == self._packed_sig and not self.model._weights_dirty:
             return
-        if self.model._weights_dirty:
+        if self.model._weights_dirty or (self.f8 and self.serial % 1000 == 999):      # (and every 1 000th forward: slow drift)
             self._refresh_f8_wexp()
         mkeys = tuple(None if not lay.conv.mask_flag else (lay.conv.mask.data_ptr(), lay.conv.mask._version)
                       for lay in self.layers)
