@@ -420,7 +420,9 @@ static TileCfg pick_tile(long long M, int n, int cin_tap, int ktot, bool raw_epi
     // Few tiles (the 13x13 layers at the per-GPU batch of BASELINE configs[3], B = 32: M = 5 408 -> 43 x 4 tiles of 128 x 128
     // for N = 512, 172 workgroups on 256 CUs): 64-column tiles double the workgroups at 2/3 of the per-tile rate
     // (dgrad total at B = 32: 1.69 -> 1.65 ms per step, 6.235 -> 6.22 ms per step; nothing changes at B = 64)
-    if (t.bn == 128 && n % 64 == 0) {
+    // (round 4: also a ragged n that pads to the same width either way -- the 125 logit channels of conv23: 85 -> 170
+    // workgroups for its M = 10 816 rows; the split-operand forward of the default precision walks 3 x 1 024 channels per tile)
+    if (t.bn == 128 && (n % 64 == 0 || round_up_int(n, 64) == round_up_int(n, 128))) {
         const long long t128 = ((M + 127) / 128) * ((n + 127) / 128);
         if (t128 < 256 && 2 * t128 <= 512) t.bn = 64;
     }
