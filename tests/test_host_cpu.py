@@ -165,6 +165,18 @@ def test_fp8_correction_geometry_query():
     assert ops.tile_info(ok) == ops.tile_info(three) and ops.tile_info(ok)[3] == 2
 
 
+def test_few_tile_launches_take_64_column_tiles():
+    """Tile rule of the LDS-staged implicit GEMM (no GPU needed: a host-side query): a launch whose 128 x 128 tiles would
+    fill less than one round of the 256 CUs takes 64-column tiles -- also when the channel count is ragged but pads to the
+    same width either way (the 125 logit channels of conv23, nets.py:796-806: 85 -> 170 workgroups at B = 64)."""
+    from modelcompression_amd import ops
+    logits = ops.geom(64, 13, 13, 1, 1024, 125, 1024)
+    assert tuple(ops.tile_info(logits)[:2]) == (128, 64)
+    assert tuple(ops.tile_info(ops.geom(32, 13, 13, 1, 1024, 512, 1024))[:2]) == (128, 64)      # 43 x 4 tiles (configs[3])
+    assert tuple(ops.tile_info(ops.geom(64, 26, 26, 1, 512, 256, 512))[:2]) == (128, 128)       # 338 x 2 tiles: unchanged
+    assert tuple(ops.tile_info(ops.geom(64, 52, 52, 1, 256, 125, 256))[:2]) == (128, 128)       # ragged, but 1 352 tiles
+
+
 def test_region_loss_runs_and_has_reference_quirks():
     from modelcompression_amd.region_loss import RegionLoss
     loss = RegionLoss()
