@@ -7,6 +7,10 @@
 //     the 32 k's of row r, half h -- the MX block structure (one scale per 32 K-elements)?
 //  3. issue rate of the e2m3 form against the e4m3 form and v_mfma_f32_32x32x16_f16.
 // build + run:  hipcc --offload-arch=gfx950 -O3 -o tools/f6_probe tools/f6_probe.hip && gpurun -- ./tools/f6_probe
+// measured (MI355X, one box): 1. and 2. hold -- 0 mismatches of 1 024 exact products with uniform scales and with a different
+// e8m0 byte per (row, half) on both operands; hipcc narrows the operands to six registers itself (v[0:5], cbsz:2 blgp:2).
+// 3.: f16 2 074, e4m3 4 690, e2m3 6 719 TFLOP/s on near-constant operands (4 waves per SIMD, 4 accumulators): the e2m3 form
+// issues at 1.43x the e4m3 form here, not the 2x of the instruction's cycle count.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
