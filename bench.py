@@ -18,6 +18,8 @@ both against the oracle (`config.tolerance_mode`, `config.throughput_mode`).
 Prints ONE JSON line (rank 0).  The timed region is NOT instrumented; `roofline` comes from a separate pass of a few
 more steps in which every convolution launch is bracketed by HIP events on the launch stream (medians per launch), for
 the dominant kernel: the implicit-GEMM MFMA convolution instance of the timed engine with the largest total time.
+`roofline_weight_gradient` is the same figure for the 9-tap weight-gradient kernel, whose total time is of the same size (it
+runs on the second stream in the timed step; in the serialised rocprof summary of `profiles/` it is the first line).
 `cpu_baseline` is the oracle (PyTorch-CPU restatement of the reference) on the host cores (rank 0, N = 1 only).
 
 --workload prune measures the other half of the hot path: weight_prune(80) and quick_filter_prune(40)
@@ -566,6 +568,17 @@ def main():
             b[1] += fl * n
             b[2] += n
             b[3] += level * fl * n
+    # The 9-tap weight gradient (csrc/conv_wgrad.hip: wgrad9_kernel for the 26x26 / 13x13 layers, its wide form from 40 pixels
+    # per row) is the other kernel of the step's size: reported beside the dominant convolution instance.  An event pair of
+    # tag 'wgrad' brackets the launch AND its slab-reduction pass (mcamd_conv_wgrad is one call).
+    wg9 = {}
+    for (tag, li), (ms, n, lay) in per.items():
+        cin_eff = lay.fold_aug if lay.fold is not None else lay.cin
+        if tag == "wgrad" and lay.k == 3 and li > 0 and cin_eff % 64 == 0 and lay.n_act % 32 == 0:
+            b = wg9.setdefault("wgrad9w_kernel<64,3>" if lay.W >= 40 else "wgrad9_kernel<64>", [0.0, 0.0, 0])
+            b[0] += ms
+            b[1] += eng.conv_flops(lay) * n
+            b[2] += n
     # the dominant kernel = the implicit-GEMM instance with the largest total time
     dom_tile = max(by_tile, key=lambda t: by_tile[t][0])
     dom_ms, dom_flop, dom_n, dom_exec = by_tile[dom_tile]
@@ -711,6 +724,16 @@ def main():
                      "measured": "HIP events around every launch in %d extra steps after the timed region; per launch the "
                                  "median over those steps" % nprof},
     }
+    if wg9:
+        wk = max(wg9, key=lambda k_: wg9[k_][0])
+        wms, wfl, wn = wg9[wk]
+        res["roofline_weight_gradient"] = {
+            "bound": "mfma", "achieved": round(wfl / (wms * 1e-3) / 1e12, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(wfl / (wms * 1e-3) / 1e12 / PEAK_FP16_TFLOPS, 4), "kernel": wk + " + its slab-reduction pass",
+            "launches_per_step": wn // nprof, "avg_launch_ms": round(wms / max(wn, 1), 4),
+            "ms_per_step": round(wms / nprof, 3), "dominant_conv_instance_ms_per_step": round(dom_ms / nprof, 3),
+            "note": "the weight-gradient kernel with the largest total time, same event pass (it runs on the second stream in "
+                    "the timed step); ALGORITHMIC flops 2 M Cout Cin 9 of the launches' layers"}
     # the instrumented pass, as evidence: what the slowest single event pair was and what the host did inside it
     # (seconds spent in [event record, library call, event record]); a per-step sum of kernel times cannot exceed ~1.5 steps
     # (the timed step overlaps the weight gradients with the rest; serialised they add ~10 %)
