@@ -5,6 +5,10 @@
 // One wave per SIMD has nobody to hide behind: the reads of chunk p+1 and the LDS-DMA of chunk p+3 are issued between the
 // MFMAs of chunk p (fragments double-buffered in VGPRs), one barrier per chunk.
 // build + run:  hipcc --offload-arch=gfx950 -O3 -o tools/gemm128_probe tools/gemm128_probe.hip && gpurun -- ./tools/gemm128_probe
+// -DBUFLDS (second session of round 4): the LDS-DMA pieces as `buffer_load_dwordx4 ... offen lds` (SGPR resource + a fixed 32-bit
+// lane offset + the chunk offset as the scalar offset) instead of global_load_lds_dwordx4 with 64-bit lane addresses: 153-166 us
+// per launch either way on one box (three timed repetitions each, two runs) -- the issue cost of a piece is not its address
+// arithmetic.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -25,6 +29,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// -DBUFLDS: the same copy as buffer_load_dwordx4 ... lds -- base in an SGPR resource, a 32-bit per-lane offset that never
+// changes, the chunk offset as the instruction's scalar offset: no 64-bit address arithmetic per piece
+#ifdef BUFLDS
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+#endif
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -53,13 +64,27 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         asrc[it] = (const char*)(A + (long long)(mt * BM + row) * K + ((phys ^ swz4(row)) * 8));
         bsrc[it] = (const char*)(B + (long long)(nt * BN + row) * K + ((phys ^ swz4(row)) * 8));
     }
+#ifdef BUFLDS
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
+    int aoff[4], boff[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) aoff[it] = (int)(asrc[it] - (const char*)A), boff[it] = (int)(bsrc[it] - (const char*)B);
+#endif
     auto stage = [&](int q) {
         char* sa = smem + (q & (NST - 1)) * STAGE_BYTES;
         char* sb = sa + BM * CPR * 16;
+#ifdef BUFLDS
+#pragma unroll
+        for (int it = 0; it < 4; ++it) blds16(ra, aoff[it], q * (BK * 2), sa + (it * NT + wave * 64) * 16);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) blds16(rb, boff[it], q * (BK * 2), sb + (it * NT + wave * 64) * 16);
+#else
 #pragma unroll
         for (int it = 0; it < 4; ++it) glds16(asrc[it] + q * (BK * 2), sa + (it * NT + wave * 64) * 16);
 #pragma unroll
         for (int it = 0; it < 4; ++it) glds16(bsrc[it] + q * (BK * 2), sb + (it * NT + wave * 64) * 16);
+#endif
     };
     // fragment addresses: lane -> (row lane & 31, k8 group lane >> 5); k16 step s flips bit 1 of the chunk index
     const int lrow = lane & 31, c0 = (lane >> 5) ^ swz4(lrow);
@@ -116,8 +141,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #endif
             if (more && (m & 3) == 1) {
                 const int piece = m >> 2;      // 0..7
+#ifdef BUFLDS
+                if (piece < 4) blds16(ra, aoff[piece], koff, sa + (piece * NT + wave * 64) * 16);
+                else blds16(rb, boff[piece - 4], koff, sb + ((piece - 4) * NT + wave * 64) * 16);
+#else
                 if (piece < 4) glds16(asrc[piece] + koff, sa + (piece * NT + wave * 64) * 16);
                 else glds16(bsrc[piece - 4] + koff, sb + ((piece - 4) * NT + wave * 64) * 16);
+#endif
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
