@@ -292,6 +292,15 @@ typedef struct mcamd_act_desc {
                                   only states slim convs as a conclusion, README.md:19). */
     int32_t planes2;           /* storage form of dst2 when it differs from dst's (its consumer is another convolution);
                                   0 = `planes` */
+    void* pool_act;            /* optional (mode MCAMD_DST_POOL), NULL = none: a FULL-RESOLUTION fp16 copy of the activation,
+                                  padded NHWC / shared-halo form per pool_act_pad, pool_act_ld channels per pixel, channels
+                                  [0, C) -- what mcamd_bn_act_bwd reads instead of the raw output (mcamd_act_bwd_desc.act)
+                                  in the backward pass of a MaxPool block.  The element the pool took (the first maximum
+                                  of the four UNROUNDED activations in (h, w) scan order, nn.MaxPool2d(2, 2), reference
+                                  src/nets.py:821) is stored as the STRICT maximum of the window: a neighbour that rounds to
+                                  the same fp16 value is written one fp16 step lower (~6e-4 of the elements of a random
+                                  tensor), so that the backward pass routes the gradient where the fp32 forward did. */
+    int32_t pool_act_ld, pool_act_pad;
 } mcamd_act_desc;
 int mcamd_bn_act_fwd(const mcamd_act_desc* d, void* stream);
 
@@ -327,7 +336,12 @@ typedef struct mcamd_act_bwd_desc {
                                   dgamma of such a channel is written as 0).  With an fp32 `y` (split-operand precisions) the
                                   two passes read half the bytes; the result carries the fp16 rounding of the stored
                                   activation, as every backward tensor does (nn.BatchNorm2d + nn.LeakyReLU backward,
-                                  reference src/nets.py:802-809 under autograd). */
+                                  reference src/nets.py:802-809 under autograd).
+                                  Mode MCAMD_DST_POOL (with or without g2): `act` is the FULL-RESOLUTION fp16 copy of the block's
+                                  activation the forward pass wrote as mcamd_act_desc.pool_act (H x W, act_choff 0); the
+                                  window's argmax is the maximum of the four stored values (strict by construction there)
+                                  and every element's LeakyReLU side is the sign of its stored value (nn.MaxPool2d(2, 2)
+                                  backward, reference src/nets.py:821). */
     int32_t act_ld, act_choff, act_pad;
 } mcamd_act_bwd_desc;
 size_t mcamd_bn_act_bwd_workspace_bytes(const mcamd_act_bwd_desc* d);

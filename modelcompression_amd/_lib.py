@@ -36,7 +36,8 @@ class ActDesc(C.Structure):
                 ("dst", C.c_void_p), ("dst_ld", C.c_int32), ("dst_choff", C.c_int32),
                 ("dst2", C.c_void_p), ("dst2_ld", C.c_int32), ("dst2_choff", C.c_int32),
                 ("y_dtype", C.c_int32), ("planes", C.c_int32), ("dst_plane", C.c_int32), ("dst2_plane", C.c_int32),
-                ("dst_pad", C.c_int32), ("dst2_pad", C.c_int32), ("border", C.c_void_p), ("planes2", C.c_int32)]
+                ("dst_pad", C.c_int32), ("dst2_pad", C.c_int32), ("border", C.c_void_p), ("planes2", C.c_int32),
+                ("pool_act", C.c_void_p), ("pool_act_ld", C.c_int32), ("pool_act_pad", C.c_int32)]
 
 
 class ChanMap(C.Structure):

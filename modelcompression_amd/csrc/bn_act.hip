@@ -104,6 +104,8 @@ struct ActArgs {
     int dst_plane, dst2_plane;  // plane strides of the split (hi | lo | hi) storage, PL == 3
     int dst_pw, dst2_pw;        // halo pixels per row / rows per image of dst, dst2: 2 (padded form) or 1 (shared-halo form)
     int dst2_pl;                // storage form of dst2 (mcamd_act_desc.planes2)
+    half_t* pool_act;           // optional (pool): full-resolution fp16 activation for the backward pass (mcamd_act_desc.pool_act)
+    int pool_act_ld, pool_act_pw;
 };
 
 __device__ __forceinline__ void load8(const half_t* p, float* v) {
@@ -172,6 +174,11 @@ __device__ __forceinline__ void store_act(half_t* p, int plane, const float* v, 
         *(h8_t*)(p + plane) = lo;
         if (PL == 3) *(h8_t*)(p + 2 * plane) = hi;      // (PL == 2: the consumer wraps its third K part onto the hi plane)
     }
+}
+// the largest fp16 value below h (bit pattern; h finite, not the most negative value)
+__device__ __forceinline__ unsigned short half_prev_bits(unsigned short b) {
+    if (b == 0x0000 || b == 0x8000) return 0x8001;          // +-0 -> the smallest negative subnormal
+    return (b & 0x8000) ? (unsigned short)(b + 1) : (unsigned short)(b - 1);
 }
 // dst2 may be stored in another form than dst (its consumer is another convolution): wave-uniform switch
 template <int PL>
@@ -258,6 +265,36 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(ActArgs a) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) m[i] = fmaxf(fmaxf(act[0][i], act[1][i]), fmaxf(act[2][i], act[3][i]));
                 store_act<PL>(a.dst + dp + c8, a.dst_plane, m, a.dst_choff + c8);
+                if (a.pool_act) {
+                    // the four activations rounded to fp16, with the window's argmax (first maximum of the UNROUNDED values,
+                    // what was just pooled) as their strict maximum: a neighbour that rounds to the same fp16 value is stored
+                    // one step lower, so the backward pass finds the argmax the forward pass took from the stored values alone
+                    typedef unsigned short us8_t __attribute__((ext_vector_type(8)));
+                    us8_t hb[4];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        int arg = 0;
+                        float best = act[0][i];
+#pragma unroll
+                        for (int k = 1; k < 4; ++k) {
+                            const bool gt = act[k][i] > best;
+                            best = gt ? act[k][i] : best, arg = gt ? k : arg;
+                        }
+                        const unsigned short top = __builtin_bit_cast(unsigned short, sat_half(best));
+                        const unsigned short below = half_prev_bits(top);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned short hk = __builtin_bit_cast(unsigned short, sat_half(act[k][i]));
+                            hb[k][i] = (k != arg && hk == top) ? below : hk;
+                        }
+                    }
+                    half_t* q0 = a.pool_act + pad_off(b, 2 * ho, 2 * wo, a.H, a.W, a.pool_act_ld, a.pool_act_pw) + c8;
+                    const long long qrow = (long long)(a.W + a.pool_act_pw) * a.pool_act_ld;
+                    *(us8_t*)q0 = hb[0];
+                    *(us8_t*)(q0 + a.pool_act_ld) = hb[1];
+                    *(us8_t*)(q0 + qrow) = hb[2];
+                    *(us8_t*)(q0 + qrow + a.pool_act_ld) = hb[3];
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) store_act<PL>(a.dst + dp + k * a.C + c8, a.dst_plane, act[k], a.dst_choff + k * a.C + c8);
@@ -770,6 +807,163 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(ActBwdArgs a) {
     }
 }
 
+// MaxPool blocks WITHOUT the saved raw output (second session of round 4): as bn_plain_bwd_act_kernel recovers a PLAIN block's
+// pre-activation from the stored activation, a MaxPool block's comes from a FULL-RESOLUTION fp16 copy of its activation
+// (the forward pass writes one beside the pooled output: mcamd_act_desc.pool_act).  z = a > 0 ? a : a / slope, xhat =
+// (z - beta) / gamma; the window's argmax is the maximum of the four STORED values -- the forward pass stores them so that
+// the element it pooled (first maximum of the unrounded activations) is their strict maximum -- and the LeakyReLU side of
+// every element is the sign of its stored value (rounding keeps the sign).  Split-operand engines save y as fp32: the two passes read 2 instead of 4 bytes per
+// element (conv2 / 5 / 8 / 13 at B = 64: 0.66 GB less per step) for 2 bytes more written by the forward pass where the copy
+// did not exist.  out_k = [k == arg] dm g_z - (P z_k + Q) with P, Q of bn_plain_bwd_act_kernel; gamma == 0 channels read the
+// saved y for their dgamma sums (pass 0 only), as there.
+template <int PHASE, bool G2>
+__global__ __launch_bounds__(256) void bn_pool_bwd_act_kernel(ActBwdArgs a) {
+    const int CH = a.C >> 3, lg = __ffs(CH) - 1;        // C / 8 is a power of two (check_c)
+    const int c8 = (threadIdx.x & (CH - 1)) * 8;
+    float sc[8], sh[8], mu[8], is[8], beta[8], rg[8], P[8], Q[8], dm[8];
+    loadf8(a.scale + c8, sc);
+    loadf8(a.shift + c8, sh);
+    loadf8(a.mean + c8, mu);
+    loadf8(a.invstd + c8, is);
+    bool need_y = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        beta[i] = sh[i] + mu[i] * sc[i];                 // shift = beta - mean scale
+        rg[i] = sc[i] != 0.f ? is[i] / sc[i] : 0.f;      // 1 / gamma (scale = gamma invstd)
+        need_y |= sc[i] == 0.f;
+    }
+    need_y = need_y && PHASE == 0 && a.y != nullptr;
+    if (PHASE == 1) {
+        float c1[8], c2[8];
+        loadf8(a.coef + c8, c1);
+        loadf8(a.coef + a.C + c8, c2);
+        if (a.dy_keep) {
+            float kp[8];
+            loadf8(a.dy_keep + c8, kp);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dm[i] = kp[i] != 0.f ? sc[i] : 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dm[i] = sc[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            P[i] = dm[i] * c2[i] * rg[i];
+            Q[i] = dm[i] * c1[i] - P[i] * beta[i];
+        }
+    }
+    float sb[8], sg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sb[i] = sg[i] = 0.f;
+    float satmax = 0.f;
+    const float inv_slope = 1.0f / a.slope;
+    const int Ho = a.H >> 1, Wo = a.W >> 1, HoWo = Ho * Wo;
+    const unsigned npix = (unsigned)(a.items >> lg);                       // pooled pixels
+    const unsigned stride = (gridDim.x * 256u) >> lg;                      // pooled pixels per grid stride
+    unsigned pix = (blockIdx.x * 256u + threadIdx.x) >> lg;
+    int b = (int)(pix / (unsigned)HoWo), rem = (int)(pix - (unsigned)b * (unsigned)HoWo);
+    int ho = rem / Wo, wo = rem - ho * Wo;
+    const int sb_ = (int)(stride / (unsigned)HoWo), srem = (int)(stride - (unsigned)sb_ * (unsigned)HoWo);
+    const int sho = srem / Wo, swo = srem - sho * Wo;
+    const long long arow = (long long)(a.W + a.act_pw) * a.act_ld;          // elements per padded image row of the activation
+    const long long yrow = (long long)a.W * a.y_ld;
+    for (; pix < npix; pix += stride) {
+        const half_t* ap = a.act + pad_off(b, 2 * ho, 2 * wo, a.H, a.W, a.act_ld, a.act_pw) + a.act_choff + c8;
+        float av[4][8], gv[8];
+        load8(ap, av[0]);
+        load8(ap + a.act_ld, av[1]);
+        load8(ap + arow, av[2]);
+        load8(ap + arow + a.act_ld, av[3]);
+        load8(a.g + (long long)pix * a.g_ld + a.g_choff + c8, gv);
+        float g2v[G2 ? 4 : 1][8];
+        if (G2) {
+            const half_t* q0 = a.g2 + (((long long)b * a.H + 2 * ho) * a.W + 2 * wo) * a.g2_ld + a.g2_choff + c8;
+            const long long g2row = (long long)a.W * a.g2_ld;
+            load8(q0, g2v[0]);
+            load8(q0 + a.g2_ld, g2v[G2 ? 1 : 0]);
+            load8(q0 + g2row, g2v[G2 ? 2 : 0]);
+            load8(q0 + g2row + a.g2_ld, g2v[G2 ? 3 : 0]);
+        }
+        float yv[4][8];
+        if (need_y) {
+            const float* yf = (const float*)a.y;
+            const long long y0 = (((long long)b * a.H + 2 * ho) * a.W + 2 * wo) * a.y_ld + a.y_choff + c8;
+            loadf8(yf + y0, yv[0]);
+            loadf8(yf + y0 + a.y_ld, yv[1]);
+            loadf8(yf + y0 + yrow, yv[2]);
+            loadf8(yf + y0 + yrow + a.y_ld, yv[3]);
+        }
+        float out[4][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float z[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) z[k] = av[k][i] > 0.f ? av[k][i] : av[k][i] * inv_slope;
+            // first maximum in (h, w) scan order of the activations as the forward pass stored them
+            int arg = 0;
+            float best = av[0][i];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const bool gt = av[k][i] > best;
+                best = gt ? av[k][i] : best, arg = gt ? k : arg;
+            }
+            if (G2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float ga = (k == arg ? gv[i] : 0.f) + g2v[G2 ? k : 0][i];
+                    const float gzk = av[k][i] > 0.f ? ga : ga * a.slope;
+                    if (PHASE == 0) {
+                        sb[i] += gzk;
+                        float xh = (z[k] - beta[i]) * rg[i];
+                        if (need_y && sc[i] == 0.f) xh = (yv[k][i] - mu[i]) * is[i];
+                        sg[i] += gzk * xh;
+                    } else {
+                        const float o = dm[i] * gzk - (P[i] * z[k] + Q[i]);
+                        out[k][i] = o;
+                        satmax = fmaxf(satmax, fabsf(o));
+                    }
+                }
+            } else {
+                const float gz = best > 0.f ? gv[i] : gv[i] * a.slope;
+                if (PHASE == 0) {
+                    float zs = z[0], ys = need_y ? yv[0][i] : 0.f;
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) zs = k == arg ? z[k] : zs, ys = (need_y && k == arg) ? yv[k][i] : ys;
+                    sb[i] += gz;
+                    float xh = (zs - beta[i]) * rg[i];
+                    if (need_y && sc[i] == 0.f) xh = (ys - mu[i]) * is[i];
+                    sg[i] += gz * xh;
+                } else {
+                    const float t = dm[i] * gz;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float o = (k == arg ? t : 0.f) - (P[i] * z[k] + Q[i]);
+                        out[k][i] = o;
+                        satmax = fmaxf(satmax, fabsf(o));
+                    }
+                }
+            }
+        }
+        if (PHASE == 1) {
+            half_t* d0 = a.dy + pad_off(b, 2 * ho, 2 * wo, a.H, a.W, a.dy_ld, a.dy_pw) + a.dy_choff + c8;
+            const long long drow = (long long)(a.W + a.dy_pw) * a.dy_ld;
+            store8(d0, out[0]);
+            store8(d0 + a.dy_ld, out[1]);
+            store8(d0 + drow, out[2]);
+            store8(d0 + drow + a.dy_ld, out[3]);
+        }
+        wo += swo;
+        if (wo >= Wo) wo -= Wo, ++ho;
+        ho += sho;
+        if (ho >= Ho) ho -= Ho, ++b;
+        b += sb_;
+    }
+    if (PHASE == 1 && satmax > 65504.f && a.overflow) atomicOr(a.overflow, 1);
+    if (PHASE == 0) {
+        block_partials_to_slab(sb, sg, CH, a.slab, a.C);
+    }
+}
+
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* slab, int nblocks, int C, double count,
                                                                float inv_scale, float* dgamma, float* dbeta,
                                                                float* coef, const int* perm, int skip_from) {
@@ -936,6 +1130,11 @@ extern "C" int mcamd_bn_act_fwd(const mcamd_act_desc* d, void* stream) {
     int grid = stream_grid(a.items);
     hipStream_t st = (hipStream_t)stream;
     a.border = d->border;
+    MCAMD_REQUIRE(!d->pool_act || (d->mode == MCAMD_DST_POOL && d->pool_act_ld % 8 == 0 && d->pool_act_ld >= d->C &&
+                                   (d->pool_act_pad == 0 || d->pool_act_pad == 1)),
+                  "bn_act_fwd: pool_act goes with mode pool, pool_act_ld (%d) a multiple of 8 >= C, pool_act_pad 0 or 1", d->pool_act_ld);
+    a.pool_act = (half_t*)d->pool_act;
+    a.pool_act_ld = d->pool_act_ld, a.pool_act_pw = d->pool_act_pad ? 1 : 2;
     const int CH = d->C / 8;
     const bool fixed = CH <= 256 && 256 % CH == 0;
     const bool y32 = d->y_dtype == 1;
@@ -1012,8 +1211,9 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
     a.act_ld = d->act_ld, a.act_choff = d->act_choff;
     a.act_pw = d->act_pad ? 1 : 2;
     if (d->act) {
-        MCAMD_REQUIRE(d->mode == MCAMD_DST_PLAIN && !d->g2, "bn_act_bwd: `act` (backward from the stored activation) is for PLAIN "
-                                                          "blocks without a second gradient");
+        MCAMD_REQUIRE((d->mode == MCAMD_DST_PLAIN && !d->g2) || d->mode == MCAMD_DST_POOL,
+                      "bn_act_bwd: `act` (backward from the stored activation) is for PLAIN blocks without a second gradient "
+                      "and for MaxPool blocks (a full-resolution copy of the activation)");
         MCAMD_REQUIRE(d->act_ld % 8 == 0 && d->act_choff % 8 == 0 && d->act_choff + d->C <= d->act_ld &&
                           (d->act_pad == 0 || d->act_pad == 1),
                       "bn_act_bwd: activation slice [%d, %d) does not fit act_ld %d", d->act_choff, d->act_choff + d->C, d->act_ld);
@@ -1049,7 +1249,9 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
 #define POOL_INST(PHASE, Y32_, G2_) hipLaunchKernelGGL((bn_pool_bwd_kernel<PHASE, Y32_, G2_>), dim3(grid), dim3(256), 0, st, a)
 #define POOL_LAUNCH(PHASE)                                                                                        \
     do {                                                                                                          \
-        if (y32 && d->g2) POOL_INST(PHASE, true, true);                                                           \
+        if (a.act && d->g2) hipLaunchKernelGGL((bn_pool_bwd_act_kernel<PHASE, true>), dim3(grid), dim3(256), 0, st, a);   \
+        else if (a.act) hipLaunchKernelGGL((bn_pool_bwd_act_kernel<PHASE, false>), dim3(grid), dim3(256), 0, st, a);      \
+        else if (y32 && d->g2) POOL_INST(PHASE, true, true);                                                      \
         else if (y32) POOL_INST(PHASE, true, false);                                                              \
         else if (d->g2) POOL_INST(PHASE, false, true);                                                            \
         else POOL_INST(PHASE, false, false);                                                                      \
@@ -1058,7 +1260,8 @@ extern "C" int mcamd_bn_act_bwd(const mcamd_act_bwd_desc* d, void* workspace, si
     const bool plain_fast = MCAMD_ENV_INT("MCAMD_BN_PLAIN_FAST", 1) != 0 &&
                             d->mode == MCAMD_DST_PLAIN && !d->g2 && a.items < (1ll << 31) &&
                             (unsigned long long)grid * 256ull < (1ull << 31);
-    MCAMD_REQUIRE(!d->act || plain_fast, "bn_act_bwd: `act` needs the plain fast path (fewer than 2^31 items)");
+    MCAMD_REQUIRE(!d->act || plain_fast || pool_fast, "bn_act_bwd: `act` needs the plain / pool fast path (fewer than 2^31 items, "
+                                                      "MCAMD_BN_POOL_FAST / MCAMD_BN_PLAIN_FAST not 0)");
 #define PLAIN_LAUNCH(PHASE)                                                                                       \
     do {                                                                                                          \
         if (a.act) hipLaunchKernelGGL((bn_plain_bwd_act_kernel<PHASE>), dim3(grid), dim3(256), 0, st, a);         \

@@ -486,6 +486,15 @@ class Engine:
                     # (the split-operand fused first block never stores its raw output)
                     lay.y = None if lay.stem_split else torch.zeros(lay.M * lay.cout, dtype=torch.float32 if self.precise else ops.HALF,
                                                                     device=dev)
+                    # Split-operand TRAINING engines keep y as fp32; the backward pass of a MaxPool block reads a full-resolution
+                    # fp16 copy of the block's ACTIVATION instead (mcamd_act_bwd_desc.act, as the PLAIN blocks read their stored
+                    # activation), which the activation pass writes beside the pooled output with the pooled element as the
+                    # window's strict maximum (mcamd_act_desc.pool_act): +2 bytes per element once, -2 bytes per element in
+                    # each of the two backward passes
+                    lay.act_full = None
+                    if (self.bwd_from_act and self.precise and self.train_layout and lay.y is not None and lay.mode == L.DST_POOL
+                            and lay.border is None and lay.slope > 0.0):
+                        lay.act_full = ops.alloc_padded(B, lay.H, lay.W, ops.round_up(lay.cout, 8), dev, pad=pad_for(lay.W))
                     if lay.stem_split:
                         lay.stats = torch.zeros(ops.stem_block_stats_rows(B, lay.H, lay.W), 2, ops.round_up(lay.cout, 256), **f32)
                     elif lay.stem_f32:
@@ -1067,13 +1076,16 @@ class Engine:
                               momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps, perm=lay.perm32,
                               ones_channel=lay.ones_idx)
                 t, t2 = lay.out_t, lay.out2_t
+                af = getattr(lay, "act_full", None) if training else None
                 ops.bn_act_fwd(B, lay.H, lay.W, lay.bn_width or lay.cout, lay.y, lay.cout, 0, lay.scale, lay.shift,
                                lay.slope, lay.mode, self.bufs[t.buf], t.ld, t.choff,
                                self.bufs[t2.buf] if t2 is not None else None,
                                t2.ld if t2 is not None else 0, t2.choff if t2 is not None else 0, border=lay.border,
                                planes=self._planes_for(lay.out_id), dst_plane=t.ps, dst2_plane=t2.ps if t2 is not None else 0,
                                dst_pad=self._pad_for(t.W), dst2_pad=self._pad_for(t2.W) if t2 is not None else 0,
-                               planes2=self._planes_for(lay.out2_id) if t2 is not None else 0)
+                               planes2=self._planes_for(lay.out2_id) if t2 is not None else 0,
+                               pool_act=af, pool_act_ld=ops.round_up(lay.cout, 8) if af is not None else 0,
+                               pool_act_pad=self._pad_for(lay.W) if af is not None else 0)
                 continue
             if (not training and self.fuse_eval and lay.perm is None and lay.border is None
                     and (lay.out2_t is None or lay.mode == L.DST_POOL)
@@ -1125,6 +1137,10 @@ class Engine:
             # plane in the consumer's input buffer, 2 bytes) instead and invert LeakyReLU (mcamd_act_bwd_desc.act)
             t = lay.out_t
             act = dict(act=self.bufs[t.buf], act_ld=t.ld, act_choff=t.choff, act_pad=self._pad_for(t.W))
+        elif self.bwd_from_act and self.precise and self.train_layout and lay.mode == L.DST_POOL and lay.slope > 0.0:
+            # ... and a MaxPool block's read the full-resolution fp16 copy of its activation (mcamd_act_desc.pool_act)
+            if getattr(lay, "act_full", None) is not None:
+                act = dict(act=lay.act_full, act_ld=ops.round_up(lay.cout, 8), act_choff=0, act_pad=self._pad_for(lay.W))
         ops.bn_act_bwd(self.B, lay.H, lay.W, cb, lay.y, lay.cout, 0, lay.scale, lay.shift, lay.mean,
                        lay.invstd, lay.slope, lay.mode, g, g_ld, g_choff, dy, lay.cout_p, 0,
                        dgamma, dbeta, grad_scale, g2, g2_ld, g2_choff,

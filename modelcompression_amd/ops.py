@@ -308,8 +308,11 @@ def unfold_wgrad(w, mask, rows, cols, beta, slope, n, cin_k, dwaug, dw, prod_dbe
 
 
 def bn_act_fwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, slope, mode, dst, dst_ld, dst_choff=0, dst2=None,
-               dst2_ld=0, dst2_choff=0, border=None, planes=1, dst_plane=0, dst2_plane=0, dst_pad=0, dst2_pad=0, planes2=0):
+               dst2_ld=0, dst2_choff=0, border=None, planes=1, dst_plane=0, dst2_plane=0, dst_pad=0, dst2_pad=0, planes2=0,
+               pool_act=None, pool_act_ld=0, pool_act_pad=0):
     """`border`: optional fp32 [16, C] table added to the raw conv output by border class (slim models).
+    `pool_act` (mode pool): padded fp16 buffer that receives the full-resolution activation for the block's backward pass
+    (mcamd_act_desc.pool_act; bn_act_bwd(..., act=pool_act)).
     `y` may be fp16 or fp32 (conv_fwd_raw / conv_fwd_raw32).  planes=3: split (hi | lo | hi) activation storage of
     the "fp16x3" precision mode with plane strides dst_plane / dst2_plane (include/mcamd.h, mcamd_act_desc.planes)."""
     d = ActDesc()
@@ -326,6 +329,8 @@ def bn_act_fwd(B, H, W, C_, y, y_ld, y_choff, scale, shift, slope, mode, dst, ds
         if border.dtype != torch.float32 or tuple(border.shape) != (16, C_) or not border.is_contiguous():
             raise L.McamdError("bn_act_fwd: border table must be contiguous fp32 [16, %d]" % C_)
         d.border = border.data_ptr()
+    if pool_act is not None:
+        d.pool_act, d.pool_act_ld, d.pool_act_pad = pool_act.data_ptr(), pool_act_ld, pool_act_pad
     check(L.lib().mcamd_bn_act_fwd(C.byref(d), stream_ptr()), "mcamd_bn_act_fwd")
 
 

@@ -988,6 +988,89 @@ def test_bn_plain_bwd_from_stored_activation(dev, C, B, H, W, pad, slope):
     assert rel_l2(dg1[ok].double() * 2.0, gm.grad[ok]) < 2e-3 and rel_l2(db1.double() * 2.0, bt.grad) < 1e-4
 
 
+
+@pytest.mark.parametrize("C,B,H,W,pad,dual", [(64, 3, 20, 12, 0, False), (128, 2, 26, 26, 1, True), (32, 2, 8, 8, 1, False)])
+def test_bn_pool_bwd_from_stored_activation(dev, C, B, H, W, pad, dual):
+    """mcamd_act_desc.pool_act + mcamd_act_bwd_desc.act in mode POOL (bn_pool_bwd_act_kernel): the BatchNorm + LeakyReLU +
+    MaxPool(2,2) backward of a block from a full-resolution fp16 copy of its activation instead of the saved fp32 raw
+    output.  The forward pass stores the copy so that the element it pooled -- the first maximum of the UNROUNDED
+    activations -- is the window's strict maximum (a neighbour that rounds to the same fp16 value goes one step lower):
+    checked element by element, with windows built to tie after rounding.  The backward pass then routes every gradient
+    where the fp32-y kernel routes it: dbeta equal to 1e-5, dY within 2e-3 (the fp16 rounding of the activation), dgamma
+    1e-3; a pruned filter, a gamma == 0 channel and (dual) the second full-resolution gradient of conv13's route included;
+    float64 autograd of nn.BatchNorm2d + LeakyReLU + nn.MaxPool2d(2, 2) (reference src/nets.py:802-821) on the same y."""
+    gen = torch.Generator().manual_seed(23 + C)
+    M, slope = B * H * W, 0.1
+    y4 = torch.randn(B, H, W, C, generator=gen) * 0.7 + 0.4
+    # windows whose two largest activations differ by less than an fp16 step (the later element the larger one), and exact ties
+    y4[:, 0::2, 0::2, :C // 2] = y4[:, 0::2, 1::2, :C // 2].abs() + 2.0
+    y4[:, 0::2, 1::2, :C // 2] = y4[:, 0::2, 0::2, :C // 2] * (1.0 + 3e-5)
+    y4[:, 1::2, 1::2, :4] = y4[:, 0::2, 1::2, :4]
+    y = y4.reshape(M, C).to(dev)
+    mean = y.mean(0)
+    invstd = 1.0 / torch.sqrt(y.var(0, unbiased=False) + 1e-5)
+    gamma = (torch.rand(C, generator=gen) + 0.5).to(dev)
+    gamma[3] = 0.0
+    beta = (torch.randn(C, generator=gen) * 0.2).to(dev)
+    scale = (gamma * invstd).contiguous()
+    shift = (beta - mean * scale).contiguous()
+    keep = torch.ones(C, device=dev)
+    keep[7] = 0.0
+    g = (torch.randn(M // 4, C, generator=gen) * 3).half().to(dev)
+    g2 = torch.randn(M, C, generator=gen).half().to(dev) if dual else None
+    Ho, Wo = H // 2, W // 2
+    pooled = ops.alloc_padded(B, Ho, Wo, 2 * C, dev)
+    route = ops.alloc_padded(B, H, W, 2 * C, dev, pad=pad) if dual else None
+    ald = C + 8
+    abuf = ops.alloc_padded(B, H, W, ald, dev, pad=pad)
+    ops.bn_act_fwd(B, H, W, C, y.reshape(-1), C, 0, scale, shift, slope, L.DST_POOL, pooled, 2 * C, 0, route, 2 * C if dual else 0, 0,
+                   planes=2, dst_plane=C, dst2_plane=C if dual else 0, dst2_pad=pad, pool_act=abuf, pool_act_ld=ald, pool_act_pad=pad)
+    # the stored copy against torch: fp16 of the activation, the pooled element strictly largest
+    # (the kernel's z = fma(y, scale, shift): one rounding -- emulated through float64 so that no element rounds to another fp16)
+    z32 = (y.double() * scale.double() + shift.double()).float()
+    a32 = torch.where(z32 > 0, z32, z32 * slope).view(B, H, W, C)
+    st = ops.padded_view(abuf, B, H, W, ald, pad=pad)[:, 1:-1, 1:-1, :C]
+    win = lambda t: t.reshape(B, Ho, 2, Wo, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Ho, Wo, 4, C)
+    aw, sw = win(a32), win(st).float()
+    assert float((sw.amax(3) - aw.amax(3).half().float()).abs().max()) == 0.0                  # the pooled value is stored as rounded
+    assert int((sw == sw.amax(3, keepdim=True)).sum(3).max()) == 1                             # ... and is the strict maximum
+    moved = sw != aw.half().float()
+    assert 0 < int(moved.sum()) < 0.3 * moved.numel()
+    step = (aw.half().float().abs() * 2.0 ** -10).clamp_min(2.0 ** -24)
+    assert bool(((sw - aw.half().float()).abs() <= step)[moved].all())                         # one fp16 step, downwards
+    assert bool((sw <= aw.half().float()).all())
+    if dual:      # the route copy is untouched by all this: the plain split storage of the activation
+        rv = ops.padded_view(route, B, H, W, 2 * C, pad=pad)[:, 1:-1, 1:-1]
+        assert torch.equal(rv[..., :C], a32.half())
+    res = []
+    for use_act in (False, True):
+        dy = ops.alloc_padded(B, H, W, C, dev, pad=pad)
+        dgm, dbt = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        kw = dict(act=abuf, act_ld=ald, act_choff=0, act_pad=pad) if use_act else {}
+        ops.bn_act_bwd(B, H, W, C, y.reshape(-1), C, 0, scale, shift, mean.contiguous(), invstd.contiguous(), slope, L.DST_POOL,
+                       g, C, 0, dy, C, 0, dgm, dbt, grad_scale=2.0, g2=g2, g2_ld=C if dual else 0, dy_keep=keep, dy_pad=pad, **kw)
+        res.append((ops.padded_view(dy, B, H, W, C, pad=pad)[:, 1:-1, 1:-1].float().cpu(), dgm.cpu(), dbt.cpu()))
+    (dy0, dg0, db0), (dy1, dg1, db1) = res
+    ok = torch.ones(C, dtype=torch.bool)
+    ok[3] = False
+    assert rel_l2(db1, db0) < 1e-5
+    assert rel_l2(dg1[ok], dg0[ok]) < 1e-3
+    assert abs(float(dg1[3] - dg0[3])) <= 1e-5 * abs(float(dg0[3])) + 1e-6
+    assert rel_l2(dy1, dy0) < 2e-3
+    assert float(dy1[..., 7].abs().max()) == 0.0 and float(dy1[..., 3].abs().max()) == 0.0
+    # float64 autograd on the same y
+    yd = y.double().cpu().view(B, H, W, C).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    gm, bt = gamma.double().cpu().requires_grad_(True), beta.double().cpu().requires_grad_(True)
+    a = F.leaky_relu(F.batch_norm(yd, None, None, gm, bt, True, 0.0, 1e-5), slope)
+    loss = (F.max_pool2d(a, 2, 2) * g.double().cpu().view(B, Ho, Wo, C).permute(0, 3, 1, 2)).sum()
+    if dual:
+        loss = loss + (a * g2.double().cpu().view(B, H, W, C).permute(0, 3, 1, 2)).sum()
+    loss.backward()
+    ref = yd.grad.permute(0, 2, 3, 1) * keep.double().cpu()
+    assert rel_l2(dy1.double(), ref) < 3e-3
+    assert rel_l2(dg1[ok].double() * 2.0, gm.grad[ok]) < 2e-3 and rel_l2(db1.double() * 2.0, bt.grad) < 1e-4
+
+
 def test_bn_coeffs_eval(dev):
     C = 64
     gamma, beta = torch.rand(C) + 0.5, torch.randn(C)
