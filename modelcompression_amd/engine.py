@@ -172,6 +172,7 @@ class Engine:
         self.f8 = precision == "mixed" and os.environ.get("MCAMD_F8", "1") == "1"
         self.bn_narrow_on = True      # BatchNorm / activation passes of a folded producer on its kept channels only
         self.bwd_from_act = True      # split-operand engines: BatchNorm backward of PLAIN blocks from the stored activation
+        self.pool_act_on = True       # ... and of MaxPool blocks from a full-resolution copy (off with filter compaction)
         self._side_stream = None
         self._side_concurrent = True
         self._side_ws = None
@@ -490,7 +491,10 @@ class Engine:
                     # fp16 copy of the block's ACTIVATION instead (mcamd_act_bwd_desc.act, as the PLAIN blocks read their stored
                     # activation), which the activation pass writes beside the pooled output with the pooled element as the
                     # window's strict maximum (mcamd_act_desc.pool_act): +2 bytes per element once, -2 bytes per element in
-                    # each of the two backward passes
+                    # each of the two backward passes (dense B=64 step 11.69 -> 11.56 ms, A/B on one box).  NOT with filter
+                    # compaction (self.pool_act_on, _update_compaction): there the weight-gradient stream is the longer one of
+                    # the backward pass, the bytes saved on the launch stream buy nothing and the forward's extra write is paid
+                    # (filter40: 8.29 -> 8.37 ms with it, same box)
                     lay.act_full = None
                     if (self.bwd_from_act and self.precise and self.train_layout and lay.y is not None and lay.mode == L.DST_POOL
                             and lay.border is None and lay.slope > 0.0):
@@ -836,6 +840,7 @@ class Engine:
             else:
                 tperm[ind] = None
         wbytes = max(wbytes, self._plan_folds())
+        self.pool_act_on = not any(lay.perm is not None for lay in self.layers)
         if wbytes > self.wgrad_ws.numel():
             self.wgrad_ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
 
@@ -1076,7 +1081,7 @@ class Engine:
                               momentum=bn.momentum if bn.momentum is not None else 0.1, eps=bn.eps, perm=lay.perm32,
                               ones_channel=lay.ones_idx)
                 t, t2 = lay.out_t, lay.out2_t
-                af = getattr(lay, "act_full", None) if training else None
+                af = getattr(lay, "act_full", None) if (training and self.pool_act_on) else None
                 ops.bn_act_fwd(B, lay.H, lay.W, lay.bn_width or lay.cout, lay.y, lay.cout, 0, lay.scale, lay.shift,
                                lay.slope, lay.mode, self.bufs[t.buf], t.ld, t.choff,
                                self.bufs[t2.buf] if t2 is not None else None,
@@ -1139,7 +1144,7 @@ class Engine:
             act = dict(act=self.bufs[t.buf], act_ld=t.ld, act_choff=t.choff, act_pad=self._pad_for(t.W))
         elif self.bwd_from_act and self.precise and self.train_layout and lay.mode == L.DST_POOL and lay.slope > 0.0:
             # ... and a MaxPool block's read the full-resolution fp16 copy of its activation (mcamd_act_desc.pool_act)
-            if getattr(lay, "act_full", None) is not None:
+            if self.pool_act_on and getattr(lay, "act_full", None) is not None:
                 act = dict(act=lay.act_full, act_ld=ops.round_up(lay.cout, 8), act_choff=0, act_pad=self._pad_for(lay.W))
         ops.bn_act_bwd(self.B, lay.H, lay.W, cb, lay.y, lay.cout, 0, lay.scale, lay.shift, lay.mean,
                        lay.invstd, lay.slope, lay.mode, g, g_ld, g_choff, dy, lay.cout_p, 0,
